@@ -1,0 +1,139 @@
+/*
+ * rnnt_engine.h — C ABI of librnnt_engine.so, the MI355X (gfx950) RNN-T joint + transducer
+ * loss engine.  Plain pointers and sizes only; no torch types cross this boundary.
+ *
+ * The reference (jakepoz/rnnt) has NO native/FFI layer: its boundary for this path is the
+ * Python pair
+ *     rnnt.joint.JointNetwork.forward            /root/reference/rnnt/joint.py:25-39
+ *     torchaudio.functional.rnnt_loss(...)       /root/reference/rnnt/model.py:35-41
+ * followed by loss.backward()                    /root/reference/rnnt/train.py:133-134.
+ * Each entry point below names the reference interface it replaces.  The Python host side
+ * (rnnt_amd/engine.py) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller owns all
+ *     memory (inputs, outputs, workspace); the library never allocates or frees device
+ *     memory and keeps no pointer after a call returns;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and returns without synchronising;
+ *   - return value 0 = success, negative = error (RNNT_ERR_*); the message is available
+ *     from rnnt_engine_last_error() (thread-local);
+ *   - lattice layout: logits [B,T,U1,V] row-major contiguous, U1 = max target length + 1;
+ *     targets [B,U1-1] int32, blank never appears in targets; lengths int32 [B].
+ */
+#ifndef RNNT_ENGINE_H
+#define RNNT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNNT_ENGINE_VERSION 1
+
+#define RNNT_DTYPE_F32 0 /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out */
+
+#define RNNT_OK 0
+#define RNNT_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim, bad blank ...        */
+#define RNNT_ERR_UNSUPPORTED (-2) /* dims the kernels do not cover (H%4, V%4, U1>1024 ...) */
+#define RNNT_ERR_WORKSPACE (-3)   /* workspace too small                                   */
+#define RNNT_ERR_LAUNCH (-4)      /* HIP reported an error at launch                       */
+
+/* Library version (RNNT_ENGINE_VERSION it was built with). */
+int rnnt_engine_version(void);
+
+/* Message of the last error on the calling thread ("" if none). */
+const char *rnnt_engine_last_error(void);
+
+/* Bytes of device workspace rnnt_engine_joint_loss_fwd_bwd needs for these dims. */
+int rnnt_engine_workspace_bytes(int B, int T, int U1, int H, int V, int dtype, size_t *out);
+
+/* Bytes of device workspace rnnt_engine_loss_fwd_bwd needs for these dims. */
+int rnnt_engine_loss_workspace_bytes(int B, int T, int U1, int V, int dtype, size_t *out);
+
+/* Bytes of device workspace rnnt_engine_joint_fwd needs for these dims. */
+int rnnt_engine_joint_fwd_workspace_bytes(int B, int T, int U1, int H, int V, int dtype,
+                                          size_t *out);
+
+/*
+ * logits[b,t,u,:] = tanh(enc[b,t,:] + pred[b,u,:]) @ W^T + bias
+ * Replaces JointNetwork.forward's last three statements, reference rnnt/joint.py:32-39
+ * (the optional audio_ln/text_ln projections of joint.py:26-30 stay with the caller).
+ *   enc   [B,T,H] with element strides enc_strides[3] (the reference hands a permuted,
+ *         non-contiguous view: rnnt/model.py:28); pred [B,U1,H] contiguous;
+ *   W     [V,H] (torch.nn.Linear layout, joint.py:18); bias [V]; logits [B,T,U1,V] out.
+ */
+int rnnt_engine_joint_fwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                          const void *W, const void *bias, int B, int T, int U1, int H, int V,
+                          int dtype, void *logits, void *workspace, size_t ws_bytes,
+                          void *stream);
+
+/*
+ * Transducer loss on given logits: per-utterance costs and d cost_b / d logits.
+ * Replaces torchaudio.functional.rnnt_loss as called at reference rnnt/model.py:35-41
+ * (fused log-softmax; `blank` already resolved to [0,V); clamp <= 0 means off).
+ *   costs [B] out; grad_logits [B,T,U1,V] out or NULL (costs only).
+ * Gradients are those of sum_b costs[b] (i.e. unscaled, as torchaudio stores them);
+ * the caller applies the reduction / upstream factor.
+ */
+int rnnt_engine_loss_fwd_bwd(const void *logits, const int32_t *targets,
+                             const int32_t *logit_lens, const int32_t *target_lens, int B,
+                             int T, int U1, int V, int blank, float clamp, int dtype,
+                             float *costs, void *grad_logits, void *workspace, size_t ws_bytes,
+                             void *stream);
+
+/*
+ * Fused joint + transducer loss, forward AND backward in one call: everything between
+ * `self.joint(...)` (reference rnnt/model.py:32) and the gradients loss.backward()
+ * (rnnt/train.py:134) delivers to the joint's inputs and parameters.
+ *   costs     [B]       per-utterance negative log-likelihood (fp32)
+ *   grad_enc  [B,T,H]   contiguous, d(mean_b costs)/d enc     (reduction="mean", model.py:41)
+ *   grad_pred [B,U1,H]  d(mean)/d pred
+ *   grad_W    [V,H]     d(mean)/d W        grad_bias [V]  d(mean)/d bias
+ * `grad_scale` multiplies every gradient (1/B for reduction="mean" on one device, 1/B_global
+ * when the batch is sharded over ranks).  The (B,T,U1,V) logits live only in `workspace`.
+ */
+int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3],
+                                   const void *pred, const void *W, const void *bias,
+                                   const int32_t *targets, const int32_t *logit_lens,
+                                   const int32_t *target_lens, int B, int T, int U1, int H,
+                                   int V, int blank, float clamp, float grad_scale, int dtype,
+                                   float *costs, void *grad_enc, void *grad_pred, void *grad_W,
+                                   void *grad_bias, void *workspace, size_t ws_bytes,
+                                   void *stream);
+
+/*
+ * Diagnostic view of the last fused call's intermediate buffers inside `workspace`
+ * (offsets in bytes; valid for the dims given).  Used by tests and bench.py to time or
+ * inspect single stages; not needed by training code.
+ */
+typedef struct rnnt_engine_ws_layout {
+    size_t logits, denom_s, lpb_s, lpe_s, alpha_s, beta_s, coef, wpack, enc_copy;
+    size_t slab_enc, slab_pred, slab_w, slab_b, total;
+    int n_ublk, n_ttile, n_split, D;
+} rnnt_engine_ws_layout;
+
+int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,
+                                 rnnt_engine_ws_layout *out);
+
+/*
+ * Run ONE stage of the fused pipeline on an already laid-out workspace (bench/profiling
+ * aid: lets bench.py time the dominant kernels with HIP events on the launch stream).
+ * stage: 0 pack+joint-forward GEMM, 1 lattice sweep (alpha & beta), 2 gradient
+ * coefficients, 3 dHidden GEMM + dEnc/dPred reduction, 4 dW GEMM + dW/db reduction.
+ * Arguments as for rnnt_engine_joint_loss_fwd_bwd.
+ */
+int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[3],
+                          const void *pred, const void *W, const void *bias,
+                          const int32_t *targets, const int32_t *logit_lens,
+                          const int32_t *target_lens, int B, int T, int U1, int H, int V,
+                          int blank, float clamp, float grad_scale, int dtype, float *costs,
+                          void *grad_enc, void *grad_pred, void *grad_W, void *grad_bias,
+                          void *workspace, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNT_ENGINE_H */

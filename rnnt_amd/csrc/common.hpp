@@ -1,0 +1,50 @@
+// common.hpp — shared device helpers for the gfx950 RNN-T engine kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RNNT_NEG_INF (-__builtin_inff())
+#define RNNT_LOG2E 1.4426950408889634f
+
+// Skewed ("anti-diagonal major") lattice layout used by every per-cell work array the
+// sweep touches: cell (b,t,u) lives at [b][d = t+u][u], D = T+U1-1 diagonals per utterance,
+// so that one anti-diagonal is contiguous in HBM (coalesced sweep loads/stores).
+__device__ __forceinline__ long skew_index(int b, int t, int u, int D, int U1)
+{
+    return ((long)b * D + (t + u)) * U1 + u;
+}
+
+// tanh via one v_exp_f32 + one v_rcp_f32: 1 - 2/(exp(2x)+1).  Saturates correctly at
+// +-inf; absolute error <~3e-7 (the result feeds a dot product, absolute error matters).
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    float e = __builtin_amdgcn_exp2f(x * (2.0f * RNNT_LOG2E));
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// 32-lane (half-wave) butterfly reductions; xor masks < 32 never cross the wave halves,
+// matching the 32x32 MFMA accumulator layout where lanes 0-31 / 32-63 hold different rows.
+__device__ __forceinline__ float half_max(float v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Packed per-cell gradient coefficients written by k_coef, read by the backward GEMMs:
+//   G[v] = exp2(logit[v]*log2e + c1) - (v==blank)*sb - (v==y)*se
+struct __attribute__((aligned(16))) CellCoef {
+    float c1;  // (alpha+beta+cost-denom+log(scale))*log2e, -inf for cells outside the lattice
+    float sb;  // blank-transition occupancy * scale
+    float se;  // emit-transition occupancy * scale
+    int y;     // emit label of this cell (targets[b][u]) or -1
+};

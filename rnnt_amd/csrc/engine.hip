@@ -1,0 +1,304 @@
+// engine.hip — C-ABI entry points of librnnt_engine.so (see include/rnnt_engine.h).
+//
+// Host-side only: argument validation, workspace carving and kernel sequencing on the
+// caller's stream.  No allocation, no synchronisation, no state kept between calls.
+#include "../../include/rnnt_engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
+{
+    if (dtype != RNNT_DTYPE_F32) return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (fp32 only)", dtype);
+    if (B <= 0 || T <= 0 || U1 <= 0 || V <= 0 || (need_h && H <= 0))
+        return fail(RNNT_ERR_INVALID_ARG, "non-positive dimension B=%d T=%d U1=%d H=%d V=%d", B, T, U1, H, V);
+    if (V % 4 != 0) return fail(RNNT_ERR_UNSUPPORTED, "V=%d must be a multiple of 4 (pad on the host side)", V);
+    if (need_h && H % 4 != 0) return fail(RNNT_ERR_UNSUPPORTED, "H=%d must be a multiple of 4 (pad on the host side)", H);
+    if (U1 > 1024) return fail(RNNT_ERR_UNSUPPORTED, "U1=%d exceeds 1024 lattice columns", U1);
+    if ((long)T * U1 > 0x7fffffffL / 2) return fail(RNNT_ERR_UNSUPPORTED, "T*U1 too large");
+    return RNNT_OK;
+}
+
+int dw_splits(int B, int T, int H, int V)
+{
+    const long tiles = (long)((V + 255) / 256) * ((H + 255) / 256);
+    long s = 256 / tiles;
+    if (s < 1) s = 1;
+    if (s > (long)B * T) s = (long)B * T;
+    return (int)s;
+}
+
+void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
+{
+    const size_t D = (size_t)T + U1 - 1;
+    const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
+    L->D = (int)D;
+    L->n_ublk = (U1 + 15) / 16;
+    L->n_ttile = (T + 7) / 8;
+    L->n_split = dw_splits(B, T, H, V);
+    size_t o = 0;
+    L->logits = o;   o += align_up(cells * V * 4);
+    L->denom_s = o;  o += align_up(skew * 4);
+    L->lpb_s = o;    o += align_up(skew * 4);
+    L->lpe_s = o;    o += align_up(skew * 4);
+    L->alpha_s = o;  o += align_up(skew * 8);
+    L->beta_s = o;   o += align_up(skew * 8);
+    L->coef = o;     o += align_up(cells * 16);
+    L->wpack = o;    o += align_up(wpack_floats(H, V) * 4);
+    L->enc_copy = o; o += align_up((size_t)B * T * H * 4);
+    L->slab_enc = o; o += align_up((size_t)L->n_ublk * B * T * H * 4);
+    L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
+    L->slab_w = o;   o += align_up((size_t)L->n_split * V * H * 4);
+    L->slab_b = o;   o += align_up((size_t)L->n_split * V * 4);
+    L->total = o;
+}
+
+int launch_status(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(RNNT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return RNNT_OK;
+}
+
+// Resolve enc into an h-contiguous, 16-byte friendly view (copying into the workspace when
+// the caller's strides do not allow 16-byte row loads, e.g. the (B,C,T)->(B,T,C) permuted
+// view of reference rnnt/model.py:28).
+void resolve_enc(const void *enc, const int64_t s[3], int B, int T, int H, float *copy_buf,
+                 hipStream_t st, const float **out, long *sb, long *st_)
+{
+    const bool direct = s[2] == 1 && (s[1] % 4) == 0 && (s[0] % 4) == 0 && aligned16(enc);
+    if (direct) {
+        *out = (const float *)enc; *sb = s[0]; *st_ = s[1];
+    } else {
+        launch_copy_enc((const float *)enc, s[0], s[1], s[2], copy_buf, B, T, H, st);
+        *out = copy_buf; *sb = (long)T * H; *st_ = H;
+    }
+}
+
+enum { ST_FWD = 1, ST_LATTICE = 2, ST_COEF = 4, ST_DH = 8, ST_DW = 16, ST_ALL = 31 };
+
+int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const void *pred,
+              const void *W, const void *bias, const int32_t *targets, const int32_t *logit_lens,
+              const int32_t *target_lens, int B, int T, int U1, int H, int V, int blank,
+              float clamp, float grad_scale, int dtype, float *costs, void *grad_enc,
+              void *grad_pred, void *grad_W, void *grad_bias, void *workspace, size_t ws_bytes,
+              void *stream)
+{
+    if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
+    if (!enc || !enc_strides || !pred || !W || !bias || !targets || !logit_lens || !target_lens ||
+        !costs || !grad_enc || !grad_pred || !grad_W || !grad_bias || !workspace)
+        return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    if (blank < 0 || blank >= V) return fail(RNNT_ERR_INVALID_ARG, "blank=%d outside [0,%d)", blank, V);
+    if (clamp > 0.f) return fail(RNNT_ERR_UNSUPPORTED, "clamp>0 is only supported by rnnt_engine_loss_fwd_bwd");
+    if (!(grad_scale > 0.f)) return fail(RNNT_ERR_INVALID_ARG, "grad_scale must be > 0");
+    if (!aligned16(pred) || !aligned16(W) || !aligned16(bias) || !aligned16(grad_enc) ||
+        !aligned16(grad_pred) || !aligned16(grad_W) || !aligned16(grad_bias) ||
+        ((uintptr_t)workspace & 255))
+        return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
+    rnnt_engine_ws_layout L;
+    layout(B, T, U1, H, V, &L);
+    if (ws_bytes < L.total)
+        return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, L.total);
+
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *logits = (float *)(ws + L.logits);
+    float *denom_s = (float *)(ws + L.denom_s), *lpb_s = (float *)(ws + L.lpb_s),
+          *lpe_s = (float *)(ws + L.lpe_s);
+    double *alpha_s = (double *)(ws + L.alpha_s), *beta_s = (double *)(ws + L.beta_s);
+    CellCoef *coef = (CellCoef *)(ws + L.coef);
+    float *wpack = (float *)(ws + L.wpack);
+
+    const float *encp; long esb, est;
+    resolve_enc(enc, enc_strides, B, T, H, (float *)(ws + L.enc_copy), st, &encp, &esb, &est);
+
+    if (stages & ST_FWD) {
+        launch_pack_w_fwd((const float *)W, wpack, H, V, st);
+        JointFwdArgs f;
+        f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred;
+        f.wpack = wpack; f.bias = (const float *)bias; f.targets = targets;
+        f.logit_lens = logit_lens; f.target_lens = target_lens; f.logits = logits;
+        f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
+        f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank;
+        launch_joint_fwd(f, st);
+    }
+    if (stages & ST_LATTICE)
+        launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D, st);
+    if (stages & ST_COEF)
+        launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
+                    B, T, U1, L.D, grad_scale, st);
+    if (stages & (ST_DH | ST_DW)) {
+        JointBwdArgs g;
+        g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred;
+        g.W = (const float *)W; g.logits = logits; g.coef = coef; g.logit_lens = logit_lens;
+        g.slab_enc = (float *)(ws + L.slab_enc); g.slab_pred = (float *)(ws + L.slab_pred);
+        g.slab_w = (float *)(ws + L.slab_w); g.slab_b = (float *)(ws + L.slab_b);
+        g.grad_enc = (float *)grad_enc; g.grad_pred = (float *)grad_pred;
+        g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
+        g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
+        g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
+        if (stages & ST_DH) launch_dhidden(g, st);
+        if (stages & ST_DW) launch_dw(g, st);
+    }
+    return launch_status("rnnt_engine fused pipeline");
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnnt_engine_version(void) { return RNNT_ENGINE_VERSION; }
+
+const char *rnnt_engine_last_error(void) { return g_err.c_str(); }
+
+int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,
+                                 rnnt_engine_ws_layout *out)
+{
+    if (!out) return fail(RNNT_ERR_INVALID_ARG, "null layout pointer");
+    if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
+    layout(B, T, U1, H, V, out);
+    return RNNT_OK;
+}
+
+int rnnt_engine_workspace_bytes(int B, int T, int U1, int H, int V, int dtype, size_t *out)
+{
+    if (!out) return fail(RNNT_ERR_INVALID_ARG, "null size pointer");
+    rnnt_engine_ws_layout L;
+    if (int rc = rnnt_engine_workspace_layout(B, T, U1, H, V, dtype, &L)) return rc;
+    *out = L.total;
+    return RNNT_OK;
+}
+
+int rnnt_engine_loss_workspace_bytes(int B, int T, int U1, int V, int dtype, size_t *out)
+{
+    if (!out) return fail(RNNT_ERR_INVALID_ARG, "null size pointer");
+    if (int rc = check_dims(B, T, U1, 4, V, dtype, false)) return rc;
+    const size_t D = (size_t)T + U1 - 1, skew = (size_t)B * D * U1, cells = (size_t)B * T * U1;
+    *out = 3 * align_up(skew * 4) + 2 * align_up(skew * 8) + align_up(cells * 16);
+    return RNNT_OK;
+}
+
+int rnnt_engine_joint_fwd_workspace_bytes(int B, int T, int U1, int H, int V, int dtype,
+                                          size_t *out)
+{
+    if (!out) return fail(RNNT_ERR_INVALID_ARG, "null size pointer");
+    if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
+    *out = align_up(wpack_floats(H, V) * 4) + align_up((size_t)B * T * H * 4);
+    return RNNT_OK;
+}
+
+int rnnt_engine_joint_fwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                          const void *W, const void *bias, int B, int T, int U1, int H, int V,
+                          int dtype, void *logits, void *workspace, size_t ws_bytes, void *stream)
+{
+    if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
+    if (!enc || !enc_strides || !pred || !W || !bias || !logits || !workspace)
+        return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    if (!aligned16(pred) || !aligned16(W) || !aligned16(bias) || !aligned16(logits) ||
+        ((uintptr_t)workspace & 255))
+        return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
+    size_t need;
+    rnnt_engine_joint_fwd_workspace_bytes(B, T, U1, H, V, dtype, &need);
+    if (ws_bytes < need) return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *wpack = (float *)ws;
+    float *enc_copy = (float *)(ws + align_up(wpack_floats(H, V) * 4));
+    const float *encp; long esb, est;
+    resolve_enc(enc, enc_strides, B, T, H, enc_copy, st, &encp, &esb, &est);
+    launch_pack_w_fwd((const float *)W, wpack, H, V, st);
+    JointFwdArgs f;
+    memset(&f, 0, sizeof f);
+    f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred; f.wpack = wpack;
+    f.bias = (const float *)bias; f.logits = (float *)logits;
+    f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = T + U1 - 1; f.blank = V - 1;
+    launch_joint_fwd(f, st);
+    return launch_status("rnnt_engine_joint_fwd");
+}
+
+int rnnt_engine_loss_fwd_bwd(const void *logits, const int32_t *targets, const int32_t *logit_lens,
+                             const int32_t *target_lens, int B, int T, int U1, int V, int blank,
+                             float clamp, int dtype, float *costs, void *grad_logits,
+                             void *workspace, size_t ws_bytes, void *stream)
+{
+    if (int rc = check_dims(B, T, U1, 4, V, dtype, false)) return rc;
+    if (!logits || !targets || !logit_lens || !target_lens || !costs || !workspace)
+        return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    if (blank < 0 || blank >= V) return fail(RNNT_ERR_INVALID_ARG, "blank=%d outside [0,%d)", blank, V);
+    if (!aligned16(logits) || (grad_logits && !aligned16(grad_logits)) || ((uintptr_t)workspace & 255))
+        return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
+    size_t need;
+    rnnt_engine_loss_workspace_bytes(B, T, U1, V, dtype, &need);
+    if (ws_bytes < need) return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, need);
+    const int D = T + U1 - 1;
+    const size_t skew = (size_t)B * D * U1;
+    char *ws = (char *)workspace;
+    float *denom_s = (float *)ws; ws += align_up(skew * 4);
+    float *lpb_s = (float *)ws;   ws += align_up(skew * 4);
+    float *lpe_s = (float *)ws;   ws += align_up(skew * 4);
+    double *alpha_s = (double *)ws; ws += align_up(skew * 8);
+    double *beta_s = (double *)ws;  ws += align_up(skew * 8);
+    CellCoef *coef = (CellCoef *)ws;
+    hipStream_t st = (hipStream_t)stream;
+    launch_logsoftmax_gather((const float *)logits, targets, logit_lens, target_lens, denom_s, lpb_s,
+                             lpe_s, B, T, U1, V, D, blank, st);
+    launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, D, st);
+    if (grad_logits) {
+        launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
+                    B, T, U1, D, 1.0f, st);
+        launch_grad_logits((const float *)logits, coef, (float *)grad_logits, (long)B * T * U1, V,
+                           blank, clamp, st);
+    }
+    return launch_status("rnnt_engine_loss_fwd_bwd");
+}
+
+int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                                   const void *W, const void *bias, const int32_t *targets,
+                                   const int32_t *logit_lens, const int32_t *target_lens, int B,
+                                   int T, int U1, int H, int V, int blank, float clamp,
+                                   float grad_scale, int dtype, float *costs, void *grad_enc,
+                                   void *grad_pred, void *grad_W, void *grad_bias, void *workspace,
+                                   size_t ws_bytes, void *stream)
+{
+    return run_fused(ST_ALL, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens, B, T,
+                     U1, H, V, blank, clamp, grad_scale, dtype, costs, grad_enc, grad_pred, grad_W,
+                     grad_bias, workspace, ws_bytes, stream);
+}
+
+int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[3],
+                          const void *pred, const void *W, const void *bias,
+                          const int32_t *targets, const int32_t *logit_lens,
+                          const int32_t *target_lens, int B, int T, int U1, int H, int V, int blank,
+                          float clamp, float grad_scale, int dtype, float *costs, void *grad_enc,
+                          void *grad_pred, void *grad_W, void *grad_bias, void *workspace,
+                          size_t ws_bytes, void *stream)
+{
+    if (stage < 0 || stage > 4) return fail(RNNT_ERR_INVALID_ARG, "stage %d outside [0,4]", stage);
+    return run_fused(1 << stage, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens,
+                     B, T, U1, H, V, blank, clamp, grad_scale, dtype, costs, grad_enc, grad_pred,
+                     grad_W, grad_bias, workspace, ws_bytes, stream);
+}
+
+}  // extern "C"

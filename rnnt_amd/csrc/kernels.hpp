@@ -1,0 +1,55 @@
+// kernels.hpp — host-side launcher declarations shared by the engine's translation units.
+#pragma once
+#include "common.hpp"
+
+// ---- lattice.hip
+void launch_logsoftmax_gather(const float *logits, const int32_t *targets,
+                              const int32_t *logit_lens, const int32_t *target_lens,
+                              float *denom_s, float *lpb_s, float *lpe_s, int B, int T, int U1,
+                              int V, int D, int blank, hipStream_t st);
+void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, double *beta_s,
+                    const int32_t *logit_lens, const int32_t *target_lens, float *costs, int B,
+                    int U1, int D, hipStream_t st);
+void launch_coef(const double *alpha_s, const double *beta_s, const float *denom_s,
+                 const float *lpb_s, const float *lpe_s, const int32_t *targets,
+                 const int32_t *logit_lens, const int32_t *target_lens, CellCoef *coef, int B,
+                 int T, int U1, int D, float scale, hipStream_t st);
+void launch_grad_logits(const float *logits, const CellCoef *coef, float *grad, long nrows,
+                        int V, int blank, float clamp, hipStream_t st);
+
+// ---- joint_fwd.hip
+struct JointFwdArgs {
+    const float *enc;   // [B,T,H], h-stride 1
+    long enc_sb, enc_st;
+    const float *pred;  // [B,U1,H] contiguous
+    const float *wpack; // packed W (pack_w_fwd)
+    const float *bias;  // [V]
+    const int32_t *targets, *logit_lens, *target_lens;  // all NULL for the plain joint
+    float *logits;      // [B,T,U1,V]
+    float *denom_s, *lpb_s, *lpe_s;  // skewed [B,D,U1]; NULL for the plain joint
+    int B, T, U1, H, V, D, blank;
+};
+size_t wpack_floats(int H, int V);
+void launch_pack_w_fwd(const float *W, float *wpack, int H, int V, hipStream_t st);
+void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st);
+void launch_copy_enc(const float *enc, long sb, long st_, long sh, float *dst, int B, int T, int H,
+                     hipStream_t st);
+
+// ---- joint_bwd.hip
+struct JointBwdArgs {
+    const float *enc; long enc_sb, enc_st;
+    const float *pred;
+    const float *W;       // [V,H] natural layout
+    const float *logits;  // [B,T,U1,V]
+    const CellCoef *coef; // [B,T,U1]
+    const int32_t *logit_lens;
+    float *slab_enc;   // [n_ublk][B,T,H]
+    float *slab_pred;  // [n_ttile][B,U1,H]
+    float *slab_w;     // [n_split][V,H]
+    float *slab_b;     // [n_split][V]
+    float *grad_enc, *grad_pred, *grad_W, *grad_bias;
+    int B, T, U1, H, V, blank;
+    int n_ublk, n_ttile, n_split;
+};
+void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
+void launch_dw(const JointBwdArgs &a, hipStream_t st);

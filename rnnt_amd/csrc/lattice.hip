@@ -1,0 +1,281 @@
+// lattice.hip — transducer-loss lattice kernels for gfx950 (HBM/latency-bound part).
+//
+// Replaces the arithmetic behind torchaudio.functional.rnnt_loss as called at reference
+// rnnt/model.py:35-41 (see SURVEY.md §8c for the recurrences):
+//   k_logsoftmax_gather  logits -> (denom, lp_blank, lp_emit) in skewed layout
+//                        (only for the standalone loss entry; the fused path gets these
+//                         from the joint-forward GEMM epilogue)
+//   k_lattice<DIR>       alpha / beta anti-diagonal wavefront sweep, one workgroup per
+//                        (utterance, direction), previous diagonal staged in LDS
+//   k_coef               per-cell gradient coefficients (CellCoef) from alpha/beta
+//   k_grad_logits        d cost / d logits, elementwise (standalone loss entry only)
+//
+// All per-cell work arrays use the skewed layout of common.hpp (anti-diagonal contiguous),
+// so every sweep load/store is a coalesced row access.  alpha/beta are kept in fp64: the
+// values reach ~1e4 in magnitude at T=1000 and the gradient needs alpha+beta+cost, a
+// cancellation fp32 cannot hold to 1e-4; the per-step log-add-exp correction term is
+// evaluated in fp32 (it is < ln 2 in magnitude).
+#include "common.hpp"
+#include "kernels.hpp"
+
+// ---------------------------------------------------------------------------------------
+// log-softmax denominators + the two log-probs each lattice cell needs.
+// One wave per (b,t,u) row; V % 4 == 0.
+__global__ __launch_bounds__(256) void k_logsoftmax_gather(
+    const float *__restrict__ logits, const int32_t *__restrict__ targets,
+    const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
+    float *__restrict__ denom_s, float *__restrict__ lpb_s, float *__restrict__ lpe_s, int B,
+    int T, int U1, int V, int D, int blank)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nrows = (long)B * T * U1;
+    if (row >= nrows) return;
+    const int u = (int)(row % U1);
+    const long bt = row / U1;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    if (t >= logit_lens[b] || u > target_lens[b]) return;
+    const float *x = logits + row * V;
+    float m = RNNT_NEG_INF;
+    for (int v = lane * 4; v < V; v += 256) {
+        f32x4 q = *(const f32x4 *)(x + v);
+        m = fmaxf(m, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])));
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    float s = 0.f;
+    for (int v = lane * 4; v < V; v += 256) {
+        f32x4 q = *(const f32x4 *)(x + v);
+        s += __expf(q[0] - m) + __expf(q[1] - m) + __expf(q[2] - m) + __expf(q[3] - m);
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k, 64);
+    if (lane == 0) {
+        const float den = m + logf(s);
+        const long si = skew_index(b, t, u, D, U1);
+        denom_s[si] = den;
+        lpb_s[si] = x[blank] - den;
+        lpe_s[si] = (u < target_lens[b]) ? x[targets[(long)b * (U1 - 1) + u]] - den : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double logaddexp_mixed(double a, double e)
+{
+    const double m = fmax(a, e);
+    if (m == (double)RNNT_NEG_INF) return m;
+    const float dl = (float)(fmin(a, e) - m);
+    return m + (double)log1pf(expf(dl));
+}
+
+// One workgroup per (utterance, direction); thread u owns lattice column u.  The previous
+// anti-diagonal is exchanged through a double-buffered LDS line (one barrier per step);
+// the lp values of the next four diagonals are prefetched into registers because they do
+// not depend on the recurrence.  DIR 0: alpha, forward over d = 0..nd-1.  DIR 1: beta,
+// backward; also emits costs[b] = -beta[0,0].
+template <int DIR>
+__global__ __launch_bounds__(1024) void k_lattice(
+    const float *__restrict__ lpb_s, const float *__restrict__ lpe_s,
+    double *__restrict__ out_s, const int32_t *__restrict__ logit_lens,
+    const int32_t *__restrict__ target_lens, float *__restrict__ costs, int U1, int D)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int NT = blockDim.x;
+    const int b = blockIdx.x;
+    const int u = threadIdx.x;
+    const int Tb = logit_lens[b];
+    const int Ub = target_lens[b];
+    const int nd = Tb + Ub;  // valid anti-diagonals 0 .. nd-1
+    double *buf[2] = {sm, sm + NT + 2};
+    const double NINF = (double)RNNT_NEG_INF;
+    buf[0][u + 1] = NINF;
+    buf[1][u + 1] = NINF;
+    if (u == 0) {
+        buf[0][0] = NINF; buf[0][NT + 1] = NINF;
+        buf[1][0] = NINF; buf[1][NT + 1] = NINF;
+    }
+    __syncthreads();
+    const long base = (long)b * D * U1;
+    const float *lpb = lpb_s + base;
+    const float *lpe = lpe_s + base;
+    double *out = out_s + base;
+    const bool col_ok = (u <= Ub);
+
+    // fetch the lp pair step k consumes (k counts steps: diagonal d = k for alpha,
+    // d = nd-1-k for beta); zero when the cell or its neighbour is outside the lattice.
+    auto fetch = [&](int k, float &lb, float &le) {
+        lb = 0.f; le = 0.f;
+        if (k >= nd) return;
+        const int d = DIR == 0 ? k : nd - 1 - k;
+        const int t = d - u;
+        if (!(col_ok && t >= 0 && t < Tb)) return;
+        if (DIR == 0) {
+            if (t > 0) lb = lpb[(long)(d - 1) * U1 + u];
+            if (u > 0) le = lpe[(long)(d - 1) * U1 + u - 1];
+        } else {
+            lb = lpb[(long)d * U1 + u];
+            if (u < Ub) le = lpe[(long)d * U1 + u];
+        }
+    };
+    auto step = [&](int k, float lb, float le) {
+        const double *prev = buf[(k & 1) ^ 1];
+        double *cur = buf[k & 1];
+        const int d = DIR == 0 ? k : nd - 1 - k;
+        const int t = d - u;
+        const bool valid = (k < nd) && col_ok && t >= 0 && t < Tb;
+        double val = NINF;
+        if (DIR == 0) {
+            const double up = prev[u + 1];  // alpha[t-1,u]
+            const double left = prev[u];    // alpha[t,u-1]
+            if (valid) {
+                if (d == 0) val = 0.0;
+                else {
+                    const double a = (t > 0) ? up + (double)lb : NINF;
+                    const double e = (u > 0) ? left + (double)le : NINF;
+                    val = logaddexp_mixed(a, e);
+                }
+            }
+        } else {
+            const double down = prev[u + 1];   // beta[t+1,u]
+            const double right = prev[u + 2];  // beta[t,u+1]
+            if (valid) {
+                if (t == Tb - 1 && u == Ub) val = (double)lb;
+                else {
+                    const double a = (t < Tb - 1) ? down + (double)lb : NINF;
+                    const double e = (u < Ub) ? right + (double)le : NINF;
+                    val = logaddexp_mixed(a, e);
+                }
+            }
+        }
+        cur[u + 1] = val;
+        if (k < nd && u < U1) out[(long)d * U1 + u] = val;
+        if (DIR == 1 && k == nd - 1 && u == 0) costs[b] = (float)(-val);
+        __syncthreads();
+    };
+
+    float lb0, le0, lb1, le1, lb2, le2, lb3, le3;
+    fetch(0, lb0, le0); fetch(1, lb1, le1); fetch(2, lb2, le2); fetch(3, lb3, le3);
+    for (int k = 0; k < nd; k += 4) {  // nd is workgroup-uniform: every thread runs the
+        step(k, lb0, le0);             // same number of barriers
+        fetch(k + 4, lb0, le0);
+        step(k + 1, lb1, le1);
+        fetch(k + 5, lb1, le1);
+        step(k + 2, lb2, le2);
+        fetch(k + 6, lb2, le2);
+        step(k + 3, lb3, le3);
+        fetch(k + 7, lb3, le3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-cell gradient coefficients.  One thread per skewed slot (b,d,u); reads are coalesced
+// rows of the skewed arrays, the 16-byte CellCoef is written at the cell's natural
+// (b,t,u) index where the GEMM kernels gather it.
+__global__ __launch_bounds__(256) void k_coef(
+    const double *__restrict__ alpha_s, const double *__restrict__ beta_s,
+    const float *__restrict__ denom_s, const float *__restrict__ lpb_s,
+    const float *__restrict__ lpe_s, const int32_t *__restrict__ targets,
+    const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
+    CellCoef *__restrict__ coef, int B, int T, int U1, int D, float scale)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)D * U1;
+    if (idx >= per * B) return;
+    const int b = (int)(idx / per);
+    const long rem = idx - (long)b * per;
+    const int d = (int)(rem / U1);
+    const int u = (int)(rem - (long)d * U1);
+    const int t = d - u;
+    if (t < 0 || t >= T) return;
+    const int Tb = logit_lens[b], Ub = target_lens[b];
+    CellCoef c;
+    c.c1 = RNNT_NEG_INF; c.sb = 0.f; c.se = 0.f; c.y = -1;
+    if (t < Tb && u <= Ub) {
+        const double a = alpha_s[idx];
+        const double cost = -beta_s[(long)b * per];
+        const double ac = a + cost;
+        c.c1 = (float)((ac + beta_s[idx] - (double)denom_s[idx] + (double)logf(scale)) *
+                       1.4426950408889634);
+        if (t < Tb - 1) c.sb = scale * expf((float)(ac + beta_s[idx + U1] + (double)lpb_s[idx]));
+        else if (u == Ub) c.sb = scale * expf((float)(ac + (double)lpb_s[idx]));
+        if (u < Ub) {
+            c.se = scale * expf((float)(ac + beta_s[idx + U1 + 1] + (double)lpe_s[idx]));
+            c.y = targets[(long)b * (U1 - 1) + u];
+        }
+    }
+    coef[((long)b * T + t) * U1 + u] = c;
+}
+
+// ---------------------------------------------------------------------------------------
+// d cost / d logits, elementwise from CellCoef (standalone loss entry).  One wave per row.
+__global__ __launch_bounds__(256) void k_grad_logits(const float *__restrict__ logits,
+                                                     const CellCoef *__restrict__ coef,
+                                                     float *__restrict__ grad, long nrows, int V,
+                                                     int blank, float clamp)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const CellCoef c = coef[row];
+    const float *x = logits + row * V;
+    float *g = grad + row * V;
+    const bool live = c.c1 != RNNT_NEG_INF;
+    for (int v = lane * 4; v < V; v += 256) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const f32x4 q = *(const f32x4 *)(x + v);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float e = __builtin_amdgcn_exp2f(fmaf(q[s], RNNT_LOG2E, c.c1));
+                if (v + s == blank) e -= c.sb;
+                if (v + s == c.y) e -= c.se;
+                if (clamp > 0.f) e = fminf(fmaxf(e, -clamp), clamp);
+                o[s] = e;
+            }
+        }
+        *(f32x4 *)(g + v) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+void launch_logsoftmax_gather(const float *logits, const int32_t *targets,
+                              const int32_t *logit_lens, const int32_t *target_lens,
+                              float *denom_s, float *lpb_s, float *lpe_s, int B, int T, int U1,
+                              int V, int D, int blank, hipStream_t st)
+{
+    const long nrows = (long)B * T * U1;
+    hipLaunchKernelGGL(k_logsoftmax_gather, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st,
+                       logits, targets, logit_lens, target_lens, denom_s, lpb_s, lpe_s, B, T, U1,
+                       V, D, blank);
+}
+
+void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, double *beta_s,
+                    const int32_t *logit_lens, const int32_t *target_lens, float *costs, int B,
+                    int U1, int D, hipStream_t st)
+{
+    const int NT = ((U1 + 63) / 64) * 64;
+    const size_t lds = 2 * (size_t)(NT + 2) * sizeof(double);
+    hipLaunchKernelGGL(k_lattice<0>, dim3(B), dim3(NT), lds, st, lpb_s, lpe_s, alpha_s,
+                       logit_lens, target_lens, costs, U1, D);
+    hipLaunchKernelGGL(k_lattice<1>, dim3(B), dim3(NT), lds, st, lpb_s, lpe_s, beta_s,
+                       logit_lens, target_lens, costs, U1, D);
+}
+
+void launch_coef(const double *alpha_s, const double *beta_s, const float *denom_s,
+                 const float *lpb_s, const float *lpe_s, const int32_t *targets,
+                 const int32_t *logit_lens, const int32_t *target_lens, CellCoef *coef, int B,
+                 int T, int U1, int D, float scale, hipStream_t st)
+{
+    const long n = (long)B * D * U1;
+    hipLaunchKernelGGL(k_coef, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, alpha_s,
+                       beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef, B,
+                       T, U1, D, scale);
+}
+
+void launch_grad_logits(const float *logits, const CellCoef *coef, float *grad, long nrows,
+                        int V, int blank, float clamp, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_grad_logits, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, logits,
+                       coef, grad, nrows, V, blank, clamp);
+}

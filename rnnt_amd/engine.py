@@ -1,0 +1,201 @@
+"""ctypes binding of librnnt_engine.so (include/rnnt_engine.h) for torch tensors.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every compute call goes
+through the C ABI.  There is NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "librnnt_engine.so")
+
+DTYPE_F32 = 0
+_lock = threading.Lock()
+_lib = None
+_workspaces = {}
+
+EXPORTS = (
+    "rnnt_engine_version", "rnnt_engine_last_error", "rnnt_engine_workspace_bytes",
+    "rnnt_engine_loss_workspace_bytes", "rnnt_engine_joint_fwd_workspace_bytes",
+    "rnnt_engine_joint_fwd", "rnnt_engine_loss_fwd_bwd", "rnnt_engine_joint_loss_fwd_bwd",
+    "rnnt_engine_workspace_layout", "rnnt_engine_run_stage",
+)
+
+
+class WsLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in (
+        "logits", "denom_s", "lpb_s", "lpe_s", "alpha_s", "beta_s", "coef", "wpack", "enc_copy",
+        "slab_enc", "slab_pred", "slab_w", "slab_b", "total")] + [
+        (n, ctypes.c_int) for n in ("n_ublk", "n_ttile", "n_split", "D")]
+
+
+def build(force: bool = False) -> str:
+    """Compile librnnt_engine.so for gfx950 with hipcc (rnnt_amd/csrc/Makefile)."""
+    cmd = ["make", "-C", _CSRC, "-j4", "-s", "librnnt_engine.so"]
+    if force:
+        cmd.insert(1, "-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """Load the engine; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"rnnt_amd: HIP engine {LIB_PATH} is missing; build it with "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU/torch fallback.")
+            L = ctypes.CDLL(LIB_PATH)
+            L.rnnt_engine_last_error.restype = ctypes.c_char_p
+            for name in EXPORTS:
+                if not hasattr(L, name):
+                    raise RuntimeError(f"rnnt_amd: {LIB_PATH} does not export {name}")
+            _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = lib().rnnt_engine_last_error().decode()
+        if rc == -1:
+            raise ValueError(f"rnnt_engine: {msg}")
+        raise RuntimeError(f"rnnt_engine error {rc}: {msg}")
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(*tensors):
+    dev = tensors[0].device
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "rnnt_amd: tensors must live on a HIP device (got %s); the engine has no CPU path"
+                % t.device)
+        if t.device != dev:
+            raise RuntimeError("rnnt_amd: all tensors must be on the same device")
+    return dev
+
+
+def workspace(device, nbytes):
+    """Grow-only per-device scratch buffer (torch owns the memory; 256-byte aligned)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _workspaces.pop(key, None)
+        ws = None
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def layout(B, T, U1, H, V):
+    L = WsLayout()
+    _check(lib().rnnt_engine_workspace_layout(B, T, U1, H, V, DTYPE_F32, ctypes.byref(L)))
+    return L
+
+
+def workspace_bytes(B, T, U1, H, V):
+    n = ctypes.c_size_t(0)
+    _check(lib().rnnt_engine_workspace_bytes(B, T, U1, H, V, DTYPE_F32, ctypes.byref(n)))
+    return n.value
+
+
+def _strides3(t):
+    return (ctypes.c_int64 * 3)(*t.stride())
+
+
+def joint_fwd(enc, pred, W, bias):
+    """logits[B,T,U1,V] = tanh(enc[:, :, None] + pred[:, None]) @ W.T + bias on the GPU
+    (reference rnnt/joint.py:32-39).  `enc` may be a non-contiguous (B,T,H) view."""
+    dev = _require_cuda(enc, pred, W, bias)
+    B, T, H = enc.shape
+    U1 = pred.shape[1]
+    V = W.shape[0]
+    pred, W, bias = pred.contiguous(), W.contiguous(), bias.contiguous()
+    logits = torch.empty((B, T, U1, V), dtype=torch.float32, device=dev)
+    n = ctypes.c_size_t(0)
+    _check(lib().rnnt_engine_joint_fwd_workspace_bytes(B, T, U1, H, V, DTYPE_F32, ctypes.byref(n)))
+    ws = workspace(dev, n.value)
+    _check(lib().rnnt_engine_joint_fwd(_p(enc), _strides3(enc), _p(pred), _p(W), _p(bias), B, T, U1,
+                                       H, V, DTYPE_F32, _p(logits), _p(ws),
+                                       ctypes.c_size_t(ws.numel()), _stream(dev)))
+    return logits
+
+
+def loss_fwd_bwd(logits, targets, logit_lens, target_lens, blank, clamp=-1.0, want_grad=True):
+    """Per-utterance costs and d(sum costs)/d logits (reference rnnt/model.py:35-41)."""
+    dev = _require_cuda(logits, targets, logit_lens, target_lens)
+    B, T, U1, V = logits.shape
+    costs = torch.empty(B, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(logits) if want_grad else None
+    n = ctypes.c_size_t(0)
+    _check(lib().rnnt_engine_loss_workspace_bytes(B, T, U1, V, DTYPE_F32, ctypes.byref(n)))
+    ws = workspace(dev, n.value)
+    _check(lib().rnnt_engine_loss_fwd_bwd(_p(logits), _p(targets), _p(logit_lens), _p(target_lens),
+                                          B, T, U1, V, int(blank), ctypes.c_float(clamp), DTYPE_F32,
+                                          _p(costs), _p(grad), _p(ws), ctypes.c_size_t(ws.numel()),
+                                          _stream(dev)))
+    return costs, grad
+
+
+def _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale, outs, ws):
+    B, T, H = enc.shape
+    U1 = pred.shape[1]
+    V = W.shape[0]
+    costs, ge, gp, gW, gb = outs
+    return (_p(enc), _strides3(enc), _p(pred), _p(W), _p(bias), _p(targets), _p(logit_lens),
+            _p(target_lens), B, T, U1, H, V, int(blank), ctypes.c_float(-1.0),
+            ctypes.c_float(grad_scale), DTYPE_F32, _p(costs), _p(ge), _p(gp), _p(gW), _p(gb),
+            _p(ws), ctypes.c_size_t(ws.numel()), _stream(enc.device))
+
+
+def alloc_fused_outputs(enc, pred, W):
+    dev = enc.device
+    B, T, H = enc.shape
+    return (torch.empty(B, dtype=torch.float32, device=dev),
+            torch.empty((B, T, H), dtype=torch.float32, device=dev),
+            torch.empty(pred.shape, dtype=torch.float32, device=dev),
+            torch.empty(W.shape, dtype=torch.float32, device=dev),
+            torch.empty(W.shape[0], dtype=torch.float32, device=dev))
+
+
+def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
+                       outs=None, stage=None):
+    """Fused joint + transducer loss forward AND backward (one C-ABI call).
+    Returns (costs[B], grad_enc, grad_pred, grad_W, grad_bias); gradients are those of
+    grad_scale * sum_b costs[b].  `stage` (0..4) runs a single pipeline stage (bench aid)."""
+    dev = _require_cuda(enc, pred, W, bias, targets, logit_lens, target_lens)
+    B, T, H = enc.shape
+    U1 = pred.shape[1]
+    V = W.shape[0]
+    if outs is None:
+        outs = alloc_fused_outputs(enc, pred, W)
+    ws = workspace(dev, workspace_bytes(B, T, U1, H, V))
+    args = _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
+                       outs, ws)
+    if stage is None:
+        _check(lib().rnnt_engine_joint_loss_fwd_bwd(*args))
+    else:
+        _check(lib().rnnt_engine_run_stage(int(stage), *args))
+    return outs

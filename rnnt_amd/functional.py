@@ -1,0 +1,186 @@
+"""Autograd-facing operators of the engine.
+
+  rnnt_loss(...)        drop-in for torchaudio.functional.rnnt_loss as the reference calls it
+                        (rnnt/model.py:35-41): same argument names, checks and error types.
+  joint_logits(...)     the T x U joint expansion of reference rnnt/joint.py:32-39.
+  joint_rnnt_loss(...)  the fused hot path: joint + loss, forward and backward in ONE engine
+                        call; the (B,T,U+1,V) logits never leave the engine's workspace.
+Every operator runs on the HIP engine; CPU tensors are rejected (no fallback).
+"""
+import torch
+
+from . import engine
+
+_PAD_NEG = -1.0e30  # bias of padded vocabulary columns: exp() underflows to exactly 0
+
+
+def _check_loss_args(T, U1, V, B, targets, logit_lengths, target_lengths, blank, reduction,
+                     check_lengths):
+    if reduction not in ("none", "mean", "sum"):
+        raise ValueError('reduction should be one of "none", "mean", or "sum"')
+    if blank < 0:
+        blank = V + blank
+    if not 0 <= blank < V:
+        raise RuntimeError("blank must be within [0, logits.shape[-1])")
+    if targets.dim() != 2:
+        raise RuntimeError("targets must have 2 dimensions")
+    if logit_lengths.dim() != 1 or target_lengths.dim() != 1:
+        raise RuntimeError("logit_lengths and target_lengths must have 1 dimension")
+    if targets.dtype != torch.int32:
+        raise RuntimeError("targets must be int32 type")
+    if logit_lengths.dtype != torch.int32 or target_lengths.dtype != torch.int32:
+        raise RuntimeError("logit_lengths and target_lengths must be int32 type")
+    if not (targets.is_contiguous() and logit_lengths.is_contiguous()
+            and target_lengths.is_contiguous()):
+        raise RuntimeError("targets, logit_lengths and target_lengths must be contiguous")
+    if logit_lengths.shape[0] != B or target_lengths.shape[0] != B or targets.shape[0] != B:
+        raise RuntimeError("batch dimension mismatch between logits, targets and lengths")
+    if targets.shape[1] != U1 - 1:
+        raise RuntimeError("targets must have max target length + 1 == logits.shape[2]")
+    if check_lengths:
+        # same host-side checks torchaudio performs (they synchronise, as torchaudio's do)
+        if int(logit_lengths.max()) != T:
+            raise RuntimeError("input length mismatch")
+        if int(target_lengths.max()) + 1 != U1:
+            raise RuntimeError("output length mismatch")
+        if int(logit_lengths.min()) < 1 or int(target_lengths.min()) < 0:
+            raise RuntimeError("lengths must be positive")
+    return blank
+
+
+class _RNNTLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, logit_lengths, target_lengths, blank, clamp):
+        costs, grad = engine.loss_fwd_bwd(logits, targets, logit_lengths, target_lengths, blank,
+                                          clamp, want_grad=logits.requires_grad)
+        ctx.save_for_backward(grad)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_costs.view(-1, 1, 1, 1), None, None, None, None, None
+
+
+def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=-1, clamp=-1, reduction="mean",
+              fused_log_softmax=True, check_lengths=True):
+    """Transducer loss on materialised logits [B,T,U+1,V] (reference rnnt/model.py:35-41)."""
+    if not fused_log_softmax:
+        raise NotImplementedError("rnnt_amd.rnnt_loss only implements fused_log_softmax=True")
+    if logits.dim() != 4:
+        raise RuntimeError("logits must have 4 dimensions")
+    if logits.dtype != torch.float32:
+        raise RuntimeError("logits must be float32 type")
+    if not logits.is_contiguous():
+        raise RuntimeError("logits must be contiguous")
+    B, T, U1, V = logits.shape
+    blank = _check_loss_args(T, U1, V, B, targets, logit_lengths, target_lengths, blank, reduction,
+                             check_lengths)
+    if V % 4 != 0:
+        pad = 4 - V % 4
+        logits = torch.nn.functional.pad(logits, (0, pad), value=_PAD_NEG)
+    costs = _RNNTLoss.apply(logits, targets, logit_lengths, target_lengths, blank, float(clamp))
+    if reduction == "mean":
+        return costs.mean()
+    if reduction == "sum":
+        return costs.sum()
+    return costs
+
+
+def _pad_hv(enc, pred, W, bias):
+    """Zero-pad H to a multiple of 4 and V to a multiple of 4 (engine requirement); padded
+    vocabulary rows get bias -1e30 so they carry zero probability and zero gradient."""
+    H, V = W.shape[1], W.shape[0]
+    ph, pv = (-H) % 4, (-V) % 4
+    if ph:
+        enc = torch.nn.functional.pad(enc, (0, ph))
+        pred = torch.nn.functional.pad(pred, (0, ph))
+        W = torch.nn.functional.pad(W, (0, ph))
+    if pv:
+        W = torch.nn.functional.pad(W, (0, 0, 0, pv))
+        bias = torch.nn.functional.pad(bias, (0, pv), value=_PAD_NEG)
+    return enc, pred, W, bias, H, V
+
+
+class _JointLogits(torch.autograd.Function):
+    """Unfused joint: HIP forward (engine.joint_fwd).  Its backward is only reached when a
+    caller asks for the (B,T,U+1,V) logits AND differentiates through them — not the
+    training hot path (that is _JointRNNTLoss) — and is expressed with torch GPU ops."""
+
+    @staticmethod
+    def forward(ctx, enc, pred, W, bias):
+        ctx.save_for_backward(enc, pred, W)
+        return engine.joint_fwd(enc, pred, W, bias)
+
+    @staticmethod
+    def backward(ctx, G):
+        enc, pred, W = ctx.saved_tensors
+        ge = torch.zeros(enc.shape, dtype=enc.dtype, device=enc.device)
+        gp = torch.zeros_like(pred)
+        gW = torch.zeros_like(W)
+        for b in range(enc.shape[0]):  # one utterance at a time bounds the hidden tensor
+            hid = torch.tanh(enc[b].unsqueeze(1) + pred[b].unsqueeze(0))
+            dh = torch.matmul(G[b], W) * (1 - hid * hid)
+            ge[b] = dh.sum(1)
+            gp[b] = dh.sum(0)
+            gW += torch.matmul(G[b].reshape(-1, G.shape[-1]).t(), hid.reshape(-1, hid.shape[-1]))
+        return ge, gp, gW, G.sum((0, 1, 2))
+
+
+def joint_logits(enc, pred, W, bias):
+    """logits = tanh(enc.unsqueeze(2) + pred.unsqueeze(1)) @ W.T + bias."""
+    if enc.dtype != torch.float32 or pred.dtype != torch.float32:
+        raise RuntimeError("rnnt_amd.joint_logits: float32 inputs required")
+    enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
+    out = _JointLogits.apply(enc_p, pred_p, W_p, bias_p)
+    return out[..., :V] if out.shape[-1] != V else out
+
+
+class _JointRNNTLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, pred, W, bias, targets, logit_lengths, target_lengths, blank, scale):
+        costs, ge, gp, gW, gb = engine.joint_loss_fwd_bwd(
+            enc, pred.contiguous(), W.contiguous(), bias.contiguous(), targets, logit_lengths,
+            target_lengths, blank, scale)
+        ctx.save_for_backward(ge, gp, gW, gb)
+        ctx.scale = scale
+        ctx.mark_non_differentiable(costs)
+        return costs.sum() * scale, costs
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_costs):
+        ge, gp, gW, gb = ctx.saved_tensors
+        return (ge * grad_loss, gp * grad_loss, gW * grad_loss, gb * grad_loss,
+                None, None, None, None, None)
+
+
+def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, blank=-1,
+                    reduction="mean", check_lengths=True, return_costs=False, grad_scale=None):
+    """Fused replacement of
+        logits = joint(enc, pred)                      # reference rnnt/model.py:32
+        loss = torchaudio.functional.rnnt_loss(logits, targets, ..., blank, clamp=-1, reduction)
+    (rnnt/model.py:35-41) including everything loss.backward() (rnnt/train.py:134) sends to
+    enc, pred, W and bias.  enc [B,T,H] (any strides), pred [B,U+1,H], W [V,H], bias [V].
+    `grad_scale` overrides the reduction factor (1/B_global when the batch is sharded)."""
+    if reduction not in ("mean", "sum"):
+        if reduction == "none":
+            raise NotImplementedError(
+                'joint_rnnt_loss supports reduction "mean" and "sum"; use joint_logits + rnnt_loss '
+                'for reduction="none"')
+        raise ValueError('reduction should be one of "none", "mean", or "sum"')
+    if enc.dim() != 3 or pred.dim() != 3:
+        raise RuntimeError("enc and pred must have 3 dimensions")
+    if enc.dtype != torch.float32 or pred.dtype != torch.float32:
+        raise RuntimeError("enc and pred must be float32 type")
+    B, T, _ = enc.shape
+    U1 = pred.shape[1]
+    V = W.shape[0]
+    if pred.shape[0] != B or pred.shape[2] != enc.shape[2] or W.shape[1] != enc.shape[2]:
+        raise RuntimeError("enc / pred / W shape mismatch")
+    blank = _check_loss_args(T, U1, V, B, targets, logit_lengths, target_lengths, blank, reduction,
+                             check_lengths)
+    enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
+    scale = float(grad_scale) if grad_scale is not None else (1.0 / B if reduction == "mean" else 1.0)
+    loss, costs = _JointRNNTLoss.apply(enc_p, pred_p, W_p, bias_p, targets, logit_lengths,
+                                       target_lengths, blank, scale)
+    return (loss, costs) if return_costs else loss

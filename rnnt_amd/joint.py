@@ -1,0 +1,51 @@
+"""JointNetwork with the constructor, attribute names and state-dict keys of the reference
+(rnnt/joint.py:4-55) whose batch `forward` runs on the HIP engine.
+
+`forward` (the T x U expansion used in training, reference joint.py:25-39) calls the engine's
+joint GEMM; `fused_loss` is the entry RNNTModel uses so that the logits are never
+materialised outside the engine; `single_forward` (decode/export, joint.py:44-55) is not on
+the hot path and stays as plain torch ops so TorchScript/ONNX export keeps working.
+"""
+import torch
+
+from . import functional as F_amd
+
+
+class JointNetwork(torch.nn.Module):
+    def __init__(self, audio_features: int, text_features: int, hidden_features: int,
+                 num_classes: int):
+        super().__init__()
+        # optional input projections exist only when the feature sizes are given, exactly as
+        # the reference decides it (joint.py:8-12); hasattr() is the switch at call time.
+        if audio_features > 0:
+            self.audio_ln = torch.nn.Linear(audio_features, hidden_features)
+        if text_features > 0:
+            self.text_ln = torch.nn.Linear(text_features, hidden_features)
+        self.activation = torch.tanh
+        self.joint_ln = torch.nn.Linear(hidden_features, num_classes)
+        self.blank_idx = num_classes - 1
+
+    def _project(self, audio_frame, text_frame):
+        if hasattr(self, "audio_ln"):
+            audio_frame = self.audio_ln(audio_frame)
+        if hasattr(self, "text_ln"):
+            text_frame = self.text_ln(text_frame)
+        return audio_frame, text_frame
+
+    def forward(self, audio_frame, text_frame):
+        """audio_frame [N,T,Fa], text_frame [N,U+1,Ft] -> logits [N,T,U+1,V]."""
+        audio_frame, text_frame = self._project(audio_frame, text_frame)
+        return F_amd.joint_logits(audio_frame, text_frame, self.joint_ln.weight, self.joint_ln.bias)
+
+    def fused_loss(self, audio_frame, text_frame, targets, logit_lengths, target_lengths,
+                   blank=-1, reduction="mean", **kw):
+        """joint + transducer loss in one engine call (reference model.py:32-41)."""
+        audio_frame, text_frame = self._project(audio_frame, text_frame)
+        return F_amd.joint_rnnt_loss(audio_frame, text_frame, self.joint_ln.weight,
+                                     self.joint_ln.bias, targets, logit_lengths, target_lengths,
+                                     blank=blank, reduction=reduction, **kw)
+
+    def single_forward(self, audio_frame, text_frame):
+        """One (audio, text) frame pair at a time: greedy decode and export (joint.py:44-55)."""
+        audio_frame, text_frame = self._project(audio_frame, text_frame)
+        return self.joint_ln(self.activation(audio_frame + text_frame))

@@ -1,0 +1,75 @@
+"""RNNTModel container with the reference's interface (rnnt/model.py:7-139); `forward`
+routes the joint + loss through the fused HIP engine.  Encoder and predictor are whatever
+torch modules the caller supplies (stock PyTorch-ROCm; out of scope for the engine).
+"""
+import inspect
+
+import torch
+
+
+class RNNTModel(torch.nn.Module):
+    def __init__(self, predictor, encoder, joint):
+        super().__init__()
+        self.predictor = predictor
+        self.encoder = encoder
+        self.joint = joint
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, mel_features: torch.Tensor, mel_feature_lens: torch.Tensor,
+                input_ids: torch.Tensor, input_id_lens: torch.Tensor,
+                blank_idx: int) -> torch.Tensor:
+        # predictor sees the targets with a leading blank (reference model.py:20-21); the loss
+        # sees the un-prepended ids (model.py:36)
+        start = torch.full((input_ids.shape[0], 1), blank_idx, dtype=input_ids.dtype,
+                           device=self.device)
+        decoder_features = self.predictor(torch.cat([start, input_ids], dim=1))
+
+        audio_features = self.encoder(mel_features).permute(0, 2, 1)  # (N,C,L) -> (N,L,C) view
+        audio_feature_lens = self.encoder.calc_output_lens(mel_feature_lens)
+
+        # reference model.py:32-41 — blank=-1, clamp=-1, reduction="mean" — as one engine call
+        return self.joint.fused_loss(audio_features, decoder_features,
+                                     targets=input_ids.int(),
+                                     logit_lengths=audio_feature_lens.int(),
+                                     target_lengths=input_id_lens.int(),
+                                     blank=-1, reduction="mean")
+
+    # ---- greedy decode (reference model.py:45-139); host loop, not on the engine's path
+    def _predictor_is_stateful(self) -> bool:
+        params = inspect.signature(self.predictor.forward).parameters
+        return len(params) >= 2
+
+    @torch.no_grad()
+    def greedy_decode(self, mel_features: torch.Tensor, mel_feature_lens: torch.Tensor,
+                      max_length: int = 200):
+        assert mel_features.shape[0] == 1, "Greedy decoding only works with a batch size of 1"
+        stateful = self._predictor_is_stateful()
+        audio = self.encoder(mel_features).permute(0, 2, 1)
+        tokens = [self.joint.blank_idx]
+        dev = self.device
+
+        def run_predictor(ids, state=None):
+            ids_t = torch.tensor([ids], dtype=torch.int64, device=dev)
+            if stateful:
+                lens = torch.tensor([len(tokens)], dtype=torch.int64, device=dev)
+                feats, _, st = (self.predictor(ids_t, lens) if state is None
+                                else self.predictor(ids_t, lens, state))
+                return feats, st
+            return self.predictor(ids_t), None
+
+        feats, state = run_predictor(tokens)
+        t, emitted = 0, 0
+        while t < audio.shape[1] and len(tokens) < max_length:
+            logits = self.joint.single_forward(audio[:, t, :], feats[:, -1, :])
+            tok = int(logits.argmax(dim=-1))
+            if tok == self.joint.blank_idx or emitted >= 10:
+                t += 1
+                emitted = 0
+            else:
+                tokens.append(tok)
+                feats, state = run_predictor([tok], state) if stateful else run_predictor(tokens)
+                emitted += 1
+        return tokens[1:]

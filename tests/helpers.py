@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests (seeded inputs, oracle calls, tolerances)."""
+import numpy as np
+
+from oracle import cpu_oracle
+
+# Parity bar (north_star: "within 1e-4 fp32"): the loss is compared RELATIVELY (fp32 cannot
+# hold 1e-4 absolute on a cost of ~1e4), gradients against the largest reference entry.
+LOSS_RTOL = 1e-4
+GRAD_RTOL = 1e-4
+GRAD_ATOL = 1e-7
+
+
+def make_inputs(B, T, U, H, V, seed, ragged=True):
+    """Synthetic inputs as SURVEY.md §8d prescribes (unit-scale enc/pred, Linear-default W)."""
+    rng = np.random.default_rng(seed)
+    k = 1.0 / np.sqrt(H)
+    d = dict(
+        enc=rng.standard_normal((B, T, H)).astype(np.float32),
+        pred=rng.standard_normal((B, U + 1, H)).astype(np.float32),
+        W=rng.uniform(-k, k, (V, H)).astype(np.float32),
+        bias=rng.uniform(-k, k, (V,)).astype(np.float32),
+        targets=rng.integers(0, V - 1, (B, max(U, 0))).astype(np.int32),
+    )
+    if ragged and B > 1:
+        ll = rng.integers(max(1, T // 2), T + 1, B)
+        tl = rng.integers(U // 2, U + 1, B)
+        ll[0], tl[0] = T, U
+    else:
+        ll, tl = np.full(B, T), np.full(B, U)
+    d["logit_lens"] = ll.astype(np.int32)
+    d["target_lens"] = tl.astype(np.int32)
+    return d
+
+
+def oracle_fused(d):
+    return cpu_oracle.joint_loss_fwd_bwd(d["enc"], d["pred"], d["W"], d["bias"], d["targets"],
+                                         d["logit_lens"], d["target_lens"], blank=-1,
+                                         dtype=np.float64)
+
+
+def assert_close_grad(name, got, ref, rtol=GRAD_RTOL, atol=GRAD_ATOL):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.isfinite(got).all(), f"{name}: non-finite values"
+    err = np.abs(got - ref).max() if got.size else 0.0
+    bound = rtol * (np.abs(ref).max() if ref.size else 0.0) + atol
+    assert err <= bound, f"{name}: max abs err {err:.3e} > {bound:.3e}"
+
+
+def assert_close_loss(name, got, ref, rtol=LOSS_RTOL):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert np.isfinite(got).all(), f"{name}: non-finite"
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12)
+    assert rel.max() <= rtol, f"{name}: rel err {rel.max():.3e} > {rtol:.1e} (got {got}, ref {ref})"
+
+
+def lgamma_paths_cost(T, U, lp_blank, lp_emit_sum):
+    """Closed form when every lattice cell has the same log-probs: all C(T+U-1, U) alignments
+    have probability exp(T*lp_blank + sum_u lp_emit[u])."""
+    from math import lgamma
+    log_paths = lgamma(T + U) - lgamma(U + 1) - lgamma(T)
+    return -(log_paths + T * lp_blank + lp_emit_sum)

@@ -1,0 +1,123 @@
+"""CPU tests: the oracle (oracle/rnnt_oracle.c) against the golden vectors produced from the
+reference's own JointNetwork, brute-force alignment enumeration and torch autograd."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import brute_force, cpu_oracle, torch_check
+from tests.helpers import assert_close_grad, lgamma_paths_cost
+
+
+def _sd(z):
+    return {k[4:].replace("__", "."): z[k] for k in z.files if k.startswith("sd__")}
+
+
+def _project(z, x, name):
+    sd = _sd(z)
+    if f"{name}.weight" in sd:
+        return x @ sd[f"{name}.weight"].T.astype(np.float64) + sd[f"{name}.bias"].astype(np.float64)
+    return x
+
+
+@pytest.mark.parametrize("name", ["joint_tiny", "joint_mid", "joint_proj", "joint_v1024"])
+def test_oracle_joint_matches_reference_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = _sd(z)
+    a = _project(z, z["audio"].astype(np.float64), "audio_ln")
+    t = _project(z, z["text"].astype(np.float64), "text_ln")
+    logits = cpu_oracle.joint_fwd(a, t, sd["joint_ln.weight"], sd["joint_ln.bias"])
+    np.testing.assert_allclose(logits, z["logits_f64"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(logits, z["logits_f32"], rtol=0, atol=2e-5)
+    ge, gp, gW, gb = cpu_oracle.joint_bwd(a, t, sd["joint_ln.weight"], z["G"])
+    if "audio_ln.weight" in sd:  # chain through the input projections
+        np.testing.assert_allclose(ge @ sd["audio_ln.weight"].astype(np.float64), z["grad_audio"], atol=1e-10)
+        np.testing.assert_allclose(gp @ sd["text_ln.weight"].astype(np.float64), z["grad_text"], atol=1e-10)
+    else:
+        np.testing.assert_allclose(ge, z["grad_audio"], atol=1e-10)
+        np.testing.assert_allclose(gp, z["grad_text"], atol=1e-10)
+    np.testing.assert_allclose(gW, z["grad__joint_ln__weight"], atol=1e-10)
+    np.testing.assert_allclose(gb, z["grad__joint_ln__bias"], atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny", "e2e_mid", "e2e_proj", "e2e_v1024"])
+def test_oracle_e2e_matches_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = _sd(z)
+    a = _project(z, z["audio"].astype(np.float64), "audio_ln")
+    t = _project(z, z["text"].astype(np.float64), "text_ln")
+    r = cpu_oracle.joint_loss_fwd_bwd(a, t, sd["joint_ln.weight"], sd["joint_ln.bias"],
+                                      z["targets"], z["logit_lens"], z["target_lens"])
+    np.testing.assert_allclose(r["loss"], z["loss"], rtol=1e-12)
+    np.testing.assert_allclose(r["costs"], z["costs"], rtol=1e-12)
+    np.testing.assert_allclose(r["grad_W"], z["grad__joint_ln__weight"], atol=1e-11)
+    np.testing.assert_allclose(r["grad_bias"], z["grad__joint_ln__bias"], atol=1e-11)
+    if "audio_ln.weight" not in sd:
+        np.testing.assert_allclose(r["grad_enc"], z["grad_audio"], atol=1e-11)
+        np.testing.assert_allclose(r["grad_pred"], z["grad_text"], atol=1e-11)
+    else:
+        np.testing.assert_allclose(r["grad_enc"] @ sd["audio_ln.weight"].astype(np.float64),
+                                   z["grad_audio"], atol=1e-11)
+
+
+@pytest.mark.parametrize("T,U,V,seed", [(1, 0, 4, 0), (1, 3, 5, 1), (4, 0, 5, 2), (4, 3, 5, 3),
+                                        (5, 4, 3, 4), (6, 2, 8, 5)])
+def test_oracle_loss_vs_bruteforce(T, U, V, seed):
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(size=(1, T, U + 1, V)) * 2
+    tg = rng.integers(0, V - 1, size=(1, max(U, 0)))
+    costs, grad = cpu_oracle.rnnt_loss(logits, tg.reshape(1, U), [T], [U])
+    ref = brute_force.nll_bruteforce(logits[0], tg[0] if U else [], T, U, V - 1)
+    assert abs(costs[0] - ref) < 1e-10
+    if T * (U + 1) * V <= 120:
+        g = brute_force.grad_bruteforce(logits[0], tg[0] if U else [], T, U, V - 1)
+        assert np.abs(grad[0] - g).max() < 1e-6
+    # every gradient row sums to zero (softmax Jacobian), SURVEY.md §8c invariant
+    assert np.abs(grad.sum(-1)).max() < 1e-12
+
+
+def test_oracle_loss_vs_autograd_ragged():
+    rng = np.random.default_rng(7)
+    B, T, U, V = 3, 9, 5, 11
+    logits = rng.normal(size=(B, T, U + 1, V))
+    tg = rng.integers(0, V - 1, size=(B, U))
+    ll, tl = np.array([9, 6, 4]), np.array([5, 2, 0])
+    costs, grad = cpu_oracle.rnnt_loss(logits, tg, ll, tl)
+    lt = torch.tensor(logits, requires_grad=True)
+    loss, c = torch_check.rnnt_loss_torch(lt, torch.tensor(tg), ll, tl, reduction="sum")
+    loss.backward()
+    np.testing.assert_allclose(costs, c.detach().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(grad, lt.grad.numpy(), atol=1e-12)
+    # cells outside each utterance's lattice carry exactly zero gradient
+    assert (grad[1, 6:] == 0).all() and (grad[1, :, 3:] == 0).all() and (grad[2, :, 1:] == 0).all()
+
+
+def test_oracle_f32_tracks_f64():
+    rng = np.random.default_rng(8)
+    B, T, U, H, V = 2, 12, 5, 32, 16
+    from tests.helpers import make_inputs, oracle_fused
+    d = make_inputs(B, T, U, H, V, 8)
+    r64 = oracle_fused(d)
+    r32 = cpu_oracle.joint_loss_fwd_bwd(d["enc"], d["pred"], d["W"], d["bias"], d["targets"],
+                                        d["logit_lens"], d["target_lens"], dtype=np.float32)
+    assert abs(r32["loss"] - r64["loss"]) / r64["loss"] < 1e-5
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r32[k], r64[k], rtol=1e-3)
+
+
+def test_closed_form_uniform_lattice():
+    """W = 0 makes every cell's logits equal to bias: cost has a closed form (used again at
+    full BASELINE size by the GPU tests)."""
+    rng = np.random.default_rng(9)
+    B, T, U, H, V = 2, 7, 3, 8, 6
+    bias = rng.normal(size=V)
+    tg = rng.integers(0, V - 1, size=(B, U))
+    r = cpu_oracle.joint_loss_fwd_bwd(rng.normal(size=(B, T, H)), rng.normal(size=(B, U + 1, H)),
+                                      np.zeros((V, H)), bias, tg, [7, 5], [3, 2])
+    lp = bias - np.log(np.exp(bias).sum())
+    for b, (Tb, Ub) in enumerate([(7, 3), (5, 2)]):
+        ref = lgamma_paths_cost(Tb, Ub, lp[V - 1], lp[tg[b, :Ub]].sum())
+        assert abs(r["costs"][b] - ref) < 1e-9
+    assert np.abs(r["grad_enc"]).max() == 0 and abs(r["grad_bias"].sum()) < 1e-12
