@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — RNN-T joint+loss lattice cells/s on MI355X (BASELINE.json metric).
+
+A "step" = one fused forward+backward of the joint + transducer loss from resident inputs
+(enc, pred, W, bias, targets, lengths) to (loss, grad_enc, grad_pred, grad_W, grad_bias):
+ONE C-ABI call (rnnt_engine_joint_loss_fwd_bwd); with N>1 ranks the utterances are sharded by
+batch (global batch fixed -> strong scaling) and one RCCL all-reduce of the flat
+[dW | db | loss] buffer follows.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+"roofline" (dominant kernel vs the fp32 MFMA peak, timed live with HIP events on the launch
+stream) and "cpu_baseline" (the CPU port of the same path on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (B, T, U, H, V)  — BASELINE.json configs
+    "cfg2": (32, 1000, 200, 512, 1024),
+    "cfg4": (8, 4000, 600, 640, 1024),
+    "cfg5": (16, 800, 150, 512, 16384),
+    "small": (8, 200, 50, 512, 1024),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def synth(B, T, U, H, V, seed, device):
+    """Synthetic inputs of SURVEY.md §8d: unit-scale enc/pred, torch-Linear-default W/bias,
+    targets uniform in [0,V-2], all lengths full so B*T*U is exact work."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    k = 1.0 / (H ** 0.5)
+    enc = torch.randn(B, T, H, generator=g)
+    pred = torch.randn(B, U + 1, H, generator=g)
+    W = (torch.rand(V, H, generator=g) * 2 - 1) * k
+    bias = (torch.rand(V, generator=g) * 2 - 1) * k
+    targets = torch.randint(0, V - 1, (B, U), generator=g, dtype=torch.int32)
+    ll = torch.full((B,), T, dtype=torch.int32)
+    tl = torch.full((B,), U, dtype=torch.int32)
+    return [x.to(device) for x in (enc, pred, W, bias, targets, ll, tl)]
+
+
+def cpu_baseline(T, U, H, V, budget_s=20.0):
+    """CPU port of the same path on this box's host cores: the reference's own torch-CPU op
+    sequence for the joint (oracle/torch_check.joint_torch == rnnt/joint.py:32-39) with torch
+    autograd, and the C restatement of the loss (oracle/rnnt_oracle.c, fp32, OpenMP over
+    utterances) standing in for torchaudio, which is absent from the image."""
+    from oracle import cpu_oracle
+    from oracle.torch_check import joint_torch
+    cpu_oracle.build()
+    threads = torch.get_num_threads()
+
+    def one(B, Tq):
+        enc, pred, W, bias, targets, ll, tl = synth(B, Tq, U, H, V, 99, "cpu")
+        enc.requires_grad_(True); pred.requires_grad_(True)
+        W.requires_grad_(True); bias.requires_grad_(True)
+        t0 = time.perf_counter()
+        logits = joint_torch(enc, pred, W, bias)
+        costs, grad = cpu_oracle.rnnt_loss(logits.detach().numpy(), targets.numpy(), ll.numpy(),
+                                           tl.numpy(), dtype=np.float32)
+        logits.backward(torch.from_numpy(grad) / B)
+        return time.perf_counter() - t0
+
+    one(1, max(8, T // 50))  # warm-up (thread pools, allocator)
+    t_probe = one(1, max(8, T // 10))
+    est_full = t_probe * 10.0
+    B = 2 if est_full * 2 <= budget_s * 1.5 else 1
+    dt = one(B, T)
+    return {"value": B * T * U / dt, "unit": "cells/s", "cores": threads, "kind": "port",
+            "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, 1 run of joint(torch CPU)+loss(C oracle) "
+                      f"fwd+bwd in {dt:.2f}s", "os_cpu_count": os.cpu_count()}
+
+
+def parity_twin(H, V, device):
+    """Loss / gradient error of a down-scaled twin of the workload against the fp64 oracle."""
+    import rnnt_amd
+    from tests.helpers import make_inputs, oracle_fused
+    d = make_inputs(2, 48, 12, H, V, seed=7)
+    t = {k: torch.from_numpy(v).to(device) for k, v in d.items()}
+    outs = rnnt_amd.engine.joint_loss_fwd_bwd(t["enc"], t["pred"], t["W"], t["bias"], t["targets"],
+                                              t["logit_lens"], t["target_lens"], V - 1, 0.5)
+    torch.cuda.synchronize()
+    ref = oracle_fused(d)
+    loss = float(outs[0].double().mean())
+    gerr = max(float(np.abs(o.cpu().numpy() - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30))
+               for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")))
+    return {"loss_rel_err": abs(loss - ref["loss"]) / abs(ref["loss"]), "grad_rel_err": gerr,
+            "twin": "B=2,T=48,U=12 ragged, same H,V, vs fp64 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    import rnnt_amd
+    from rnnt_amd import engine
+    engine.lib()
+
+    B, T, U, H, V = CONFIGS[args.config]
+    if B % world != 0:
+        raise SystemExit(f"global batch {B} not divisible by {world} ranks")
+    Bl = B // world  # contiguous batch shard per rank (strong scaling: global batch fixed)
+    enc, pred, W, bias, targets, ll, tl = synth(Bl, T, U, H, V, 1234 + rank, device)
+    if world > 1:  # parameters are replicated: rank 0's W/bias everywhere
+        dist.broadcast(W, 0); dist.broadcast(bias, 0)
+    scale = 1.0 / B
+    # flat [dW | db | loss] buffer: grad_W / grad_bias are views, so the all-reduce needs no copy
+    flat = torch.zeros(V * H + V + 4, dtype=torch.float32, device=device)
+    gW = flat[:V * H].view(V, H)
+    gb = flat[V * H:V * H + V]
+    costs = torch.empty(Bl, dtype=torch.float32, device=device)
+    ge = torch.empty(Bl, T, H, dtype=torch.float32, device=device)
+    gp = torch.empty(Bl, U + 1, H, dtype=torch.float32, device=device)
+    outs = (costs, ge, gp, gW, gb)
+
+    def step():
+        engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs)
+        flat[V * H + V] = costs.sum() * scale
+        if world > 1:
+            dist.all_reduce(flat)  # one RCCL all-reduce over xGMI: dW, db and the loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = float(flat[V * H + V].item())
+
+    # ---- per-stage timing with HIP events on the launch stream (torch's current stream IS the
+    # stream every kernel was enqueued on: engine._stream()).
+    stage_ms = None
+    if not args.no_stage_timing:
+        names = ["joint_fwd_gemm", "lattice_sweep", "grad_coef", "dhidden_gemm", "dw_gemm"]
+        reps = max(2, min(args.steps, 5))
+        stage_ms = {}
+        for s, name in enumerate(names):
+            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s)
+            e1.record(); e1.synchronize()
+            stage_ms[name] = e0.elapsed_time(e1) / reps
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    cells_local = Bl * T * U
+    cells_global = B * T * U
+    ms = dt / args.steps * 1e3
+    out = {
+        "metric": "RNN-T joint+loss fwd+bwd lattice cells/s (B*T*U/s)",
+        "value": cells_global * args.steps / dt,
+        "unit": "cells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} fp32 joint+loss fwd+bwd",
+                   "global_batch": B, "per_gpu_batch": Bl, "parallelism": f"dp{world}",
+                   "cells_BTU1": B * T * (U + 1)},
+        "loss": loss,
+    }
+    flops_cell = 6.0 * H * V  # 2HV fwd + 2HV dHidden + 2HV dW per lattice cell
+    cells1 = Bl * T * (U + 1)  # cells the GEMMs actually process per launch (U+1 columns)
+    out["path_tflops"] = flops_cell * cells1 / (dt / args.steps) / 1e12
+    if stage_ms:
+        gemms = {k: stage_ms[k] for k in ("joint_fwd_gemm", "dhidden_gemm", "dw_gemm")}
+        dom = max(gemms, key=gemms.get)
+        ach = 2.0 * H * V * cells1 / (gemms[dom] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach,
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
+        sweep_bytes = 24.0 * cells1
+        out["stages_ms"] = stage_ms
+        out["lattice_sweep"] = {"achieved_GBs": sweep_bytes / (stage_ms["lattice_sweep"] * 1e-3) / 1e9,
+                                "peak_GBs": PEAK_HBM_GBS, "bytes": sweep_bytes,
+                                "frac": sweep_bytes / (stage_ms["lattice_sweep"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if world == 1:
+        try:
+            out["parity"] = parity_twin(H, V, device)
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            engine.release_workspaces()
+            out["cpu_baseline"] = cpu_baseline(T, U, H, V)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

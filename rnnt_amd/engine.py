@@ -75,6 +75,14 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _nonempty(targets):
+    """U = 0 (no labels) gives an empty [B,0] tensor whose data_ptr is NULL; the ABI wants a
+    valid pointer, the kernels never dereference it in that case."""
+    if targets.numel() == 0:
+        return torch.zeros(1, dtype=torch.int32, device=targets.device)
+    return targets
+
+
 def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -147,6 +155,7 @@ def loss_fwd_bwd(logits, targets, logit_lens, target_lens, blank, clamp=-1.0, wa
     """Per-utterance costs and d(sum costs)/d logits (reference rnnt/model.py:35-41)."""
     dev = _require_cuda(logits, targets, logit_lens, target_lens)
     B, T, U1, V = logits.shape
+    targets = _nonempty(targets)
     costs = torch.empty(B, dtype=torch.float32, device=dev)
     grad = torch.empty_like(logits) if want_grad else None
     n = ctypes.c_size_t(0)
@@ -189,6 +198,7 @@ def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, bla
     B, T, H = enc.shape
     U1 = pred.shape[1]
     V = W.shape[0]
+    targets = _nonempty(targets)
     if outs is None:
         outs = alloc_fused_outputs(enc, pred, W)
     ws = workspace(dev, workspace_bytes(B, T, U1, H, V))

@@ -52,13 +52,15 @@ class _RNNTLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, logit_lengths, target_lengths, blank, clamp):
         costs, grad = engine.loss_fwd_bwd(logits, targets, logit_lengths, target_lengths, blank,
-                                          clamp, want_grad=logits.requires_grad)
+                                          clamp, want_grad=ctx.needs_input_grad[0])
         ctx.save_for_backward(grad)
         return costs
 
     @staticmethod
     def backward(ctx, grad_costs):
         (grad,) = ctx.saved_tensors
+        if grad is None:
+            return None, None, None, None, None, None
         return grad * grad_costs.view(-1, 1, 1, 1), None, None, None, None, None
 
 

@@ -1,0 +1,238 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI (ctypes), against the
+CPU oracle on the same seeded inputs, against the committed golden fixtures, and — at
+BASELINE.json's full sizes — through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import (assert_close_grad, assert_close_loss, lgamma_paths_cost, make_inputs,
+                           oracle_fused)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import rnnt_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    rnnt_amd.engine.lib()  # fail loudly if the HIP extension is missing
+    return rnnt_amd
+
+
+def _dev(d):
+    return {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+
+
+def _run_fused(amd, d, enc_override=None):
+    g = _dev(d)
+    enc = enc_override if enc_override is not None else g["enc"]
+    enc = enc.detach().requires_grad_(True)
+    pred = g["pred"].requires_grad_(True)
+    W = g["W"].requires_grad_(True)
+    bias = g["bias"].requires_grad_(True)
+    loss, costs = amd.joint_rnnt_loss(enc, pred, W, bias, g["targets"], g["logit_lens"],
+                                      g["target_lens"], blank=-1, reduction="mean",
+                                      return_costs=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    return dict(loss=loss.item(), costs=costs.cpu().numpy(), grad_enc=enc.grad.cpu().numpy(),
+                grad_pred=pred.grad.cpu().numpy(), grad_W=W.grad.cpu().numpy(),
+                grad_bias=bias.grad.cpu().numpy())
+
+
+def _compare(r, ref):
+    assert_close_loss("loss", r["loss"], ref["loss"])
+    assert_close_loss("costs", r["costs"], ref["costs"])
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r[k], ref[k])
+
+
+# (B, T, U, H, V): edges — single cell, U=0, T=1, ragged, H%8!=0, V%128!=0, V%4!=0, H%4!=0,
+# several u-blocks / t-tiles / forward passes / dW tiles
+FUSED_SHAPES = [
+    (1, 1, 0, 8, 4), (1, 1, 3, 8, 8), (2, 5, 0, 16, 8), (2, 5, 2, 16, 8), (3, 17, 8, 64, 32),
+    (2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 12, 5, 128, 1024), (2, 40, 33, 72, 520),
+    (2, 7, 3, 10, 7), (4, 30, 12, 520, 260), (1, 64, 40, 32, 1300),
+]
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES)
+def test_fused_joint_loss_vs_oracle(amd, shape):
+    B, T, U, H, V = shape
+    d = make_inputs(B, T, U, H, V, seed=sum(shape))
+    _compare(_run_fused(amd, d), oracle_fused(d))
+
+
+def test_fused_noncontiguous_encoder_view(amd):
+    """The reference hands the joint a permuted (B,C,T)->(B,T,C) view (rnnt/model.py:27-28)."""
+    d = make_inputs(2, 21, 6, 48, 64, seed=5)
+    enc_bct = torch.from_numpy(np.ascontiguousarray(d["enc"].transpose(0, 2, 1))).cuda()
+    view = enc_bct.permute(0, 2, 1)
+    assert not view.is_contiguous()
+    _compare(_run_fused(amd, d, enc_override=view), oracle_fused(d))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 0, 4), (2, 6, 3, 8), (3, 31, 17, 40), (2, 20, 9, 1024),
+                                   (2, 8, 4, 7), (1, 130, 70, 16)])
+def test_loss_only_vs_oracle(amd, shape):
+    """rnnt_loss on given logits == the call at reference rnnt/model.py:35-41."""
+    from oracle import cpu_oracle
+    B, T, U, V = shape
+    rng = np.random.default_rng(sum(shape))
+    logits = (rng.standard_normal((B, T, U + 1, V)) * 2).astype(np.float32)
+    d = make_inputs(B, T, U, 4, V, seed=sum(shape))
+    lt = torch.from_numpy(logits).cuda().requires_grad_(True)
+    g = _dev(d)
+    costs = amd.rnnt_loss(lt, g["targets"], g["logit_lens"], g["target_lens"], blank=-1,
+                          reduction="none")
+    w = torch.arange(1, B + 1, dtype=torch.float32, device="cuda")
+    (costs * w).sum().backward()
+    ref_c, ref_g = cpu_oracle.rnnt_loss(logits, d["targets"], d["logit_lens"], d["target_lens"])
+    assert_close_loss("costs", costs.detach().cpu().numpy(), ref_c)
+    assert_close_grad("grad_logits", lt.grad.cpu().numpy(),
+                      ref_g * np.arange(1, B + 1).reshape(B, 1, 1, 1))
+    mean = amd.rnnt_loss(lt.detach(), g["targets"], g["logit_lens"], g["target_lens"])
+    assert_close_loss("mean", mean.item(), ref_c.mean())
+
+
+def test_loss_clamp(amd):
+    from oracle import cpu_oracle
+    rng = np.random.default_rng(3)
+    logits = (rng.standard_normal((2, 7, 4, 12)) * 3).astype(np.float32)
+    d = make_inputs(2, 7, 3, 4, 12, seed=3)
+    lt = torch.from_numpy(logits).cuda().requires_grad_(True)
+    g = _dev(d)
+    amd.rnnt_loss(lt, g["targets"], g["logit_lens"], g["target_lens"], clamp=0.05,
+                  reduction="sum").backward()
+    _, ref_g = cpu_oracle.rnnt_loss(logits, d["targets"], d["logit_lens"], d["target_lens"], clamp=0.05)
+    assert_close_grad("grad_logits", lt.grad.cpu().numpy(), ref_g)
+
+
+def _sd(z):
+    return {k[4:].replace("__", "."): torch.from_numpy(z[k]) for k in z.files if k.startswith("sd__")}
+
+
+@pytest.mark.parametrize("name", ["joint_tiny", "joint_mid", "joint_proj", "joint_v1024"])
+def test_joint_forward_golden(amd, golden_dir, name):
+    """JointNetwork.forward on the engine vs logits/grads produced by the reference's own
+    rnnt.joint.JointNetwork (tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = amd.JointNetwork(*[int(x) for x in z["ctor"]]).cuda()
+    m.load_state_dict(_sd(z))
+    a = torch.from_numpy(z["audio"]).cuda().requires_grad_(True)
+    t = torch.from_numpy(z["text"]).cuda().requires_grad_(True)
+    logits = m(a, t)
+    assert_close_grad("logits", logits.detach().cpu().numpy(), z["logits_f64"], rtol=1e-5, atol=1e-5)
+    (logits * torch.from_numpy(z["G"]).cuda()).sum().backward()
+    assert_close_grad("grad_audio", a.grad.cpu().numpy(), z["grad_audio"])
+    assert_close_grad("grad_text", t.grad.cpu().numpy(), z["grad_text"])
+    for k, p in m.named_parameters():
+        assert_close_grad(k, p.grad.cpu().numpy(), z["grad__" + k.replace(".", "__")])
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny", "e2e_mid", "e2e_proj", "e2e_v1024"])
+def test_fused_golden(amd, golden_dir, name):
+    """fused_loss (joint + loss + backward in one engine call) vs the golden end-to-end
+    fixtures (reference JointNetwork in fp64 + independent autograd loss)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = amd.JointNetwork(*[int(x) for x in z["ctor"]]).cuda()
+    m.load_state_dict(_sd(z))
+    a = torch.from_numpy(z["audio"]).cuda().requires_grad_(True)
+    t = torch.from_numpy(z["text"]).cuda().requires_grad_(True)
+    loss = m.fused_loss(a, t, torch.from_numpy(z["targets"]).cuda(),
+                        torch.from_numpy(z["logit_lens"]).cuda(),
+                        torch.from_numpy(z["target_lens"]).cuda())
+    loss.backward()
+    assert_close_loss("loss", loss.item(), float(z["loss"]))
+    assert_close_grad("grad_audio", a.grad.cpu().numpy(), z["grad_audio"])
+    assert_close_grad("grad_text", t.grad.cpu().numpy(), z["grad_text"])
+    for k, p in m.named_parameters():
+        assert_close_grad(k, p.grad.cpu().numpy(), z["grad__" + k.replace(".", "__")])
+
+
+def test_model_forward_matches_unfused(amd):
+    """RNNTModel.forward (reference rnnt/model.py:17-43 call sequence) with stand-in encoder /
+    predictor modules: fused loss == joint logits -> rnnt_loss, and grads reach every module."""
+    torch.manual_seed(0)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv1d(10, 32, 3, stride=2, padding=1)
+
+        def forward(self, x):
+            return self.c(x)
+
+        def calc_output_lens(self, lens):
+            return (lens + 1) // 2
+
+    class Pred(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.e = torch.nn.Embedding(16, 32)
+
+        def forward(self, ids):
+            return self.e(ids)
+
+    model = amd.RNNTModel(Pred(), Enc(), amd.JointNetwork(-1, -1, 32, 16)).cuda()
+    mel = torch.randn(3, 10, 40, device="cuda")
+    mel_lens = torch.tensor([40, 33, 21], device="cuda")
+    ids = torch.randint(0, 15, (3, 6), device="cuda")
+    id_lens = torch.tensor([6, 4, 2], device="cuda")
+    loss = model(mel, mel_lens, ids, id_lens, 15)
+    loss.backward()
+    g_fused = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    # unfused: same modules, logits materialised, separate loss op
+    start = torch.full((3, 1), 15, dtype=ids.dtype, device="cuda")
+    dec = model.predictor(torch.cat([start, ids], 1))
+    aud = model.encoder(mel).permute(0, 2, 1)
+    logits = model.joint(aud, dec)
+    loss2 = amd.rnnt_loss(logits, ids.int(), model.encoder.calc_output_lens(mel_lens).int(),
+                          id_lens.int(), blank=-1)
+    loss2.backward()
+    assert_close_loss("loss", loss.item(), loss2.item(), rtol=1e-5)
+    for k, p in model.named_parameters():
+        assert_close_grad(k, g_fused[k].cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4)
+
+
+# ---------------------------------------------------------------- full-size properties
+def _full(amd, B, T, U, H, V, seed):
+    d = make_inputs(B, T, U, H, V, seed, ragged=False)
+    d["W"] = np.zeros_like(d["W"])  # logits == bias in every cell: closed-form loss
+    r = _run_fused(amd, d)
+    bias = d["bias"].astype(np.float64)
+    lp = bias - np.log(np.exp(bias).sum())
+    for b in range(B):
+        ref = lgamma_paths_cost(T, U, lp[V - 1], lp[d["targets"][b]].sum())
+        assert abs(r["costs"][b] - ref) / ref < 1e-5, (b, r["costs"][b], ref)
+    assert np.abs(r["grad_enc"]).max() == 0 and np.abs(r["grad_pred"]).max() == 0
+    # every gradient row sums to zero => so does grad_bias; blank column carries -T/B... total
+    assert abs(r["grad_bias"].sum()) < 1e-3 * np.abs(r["grad_bias"]).sum()
+    return r
+
+
+def test_fullsize_config2_closed_form(amd):
+    """BASELINE config 2 (B=32,T=1000,U=200,H=512,V=1024): known-answer loss at full size."""
+    _full(amd, 32, 1000, 200, 512, 1024, seed=2)
+
+
+def test_fullsize_config2_fused_vs_unfused_subset(amd):
+    """Full T,U,H,V of config 2 on 2 utterances: fused engine path vs the unfused GPU path
+    (joint GEMM -> rnnt_loss kernels -> torch-op backward): independent backward arithmetic."""
+    d = make_inputs(2, 1000, 200, 512, 1024, seed=22)
+    r = _run_fused(amd, d)
+    g = _dev(d)
+    enc = g["enc"].requires_grad_(True); pred = g["pred"].requires_grad_(True)
+    W = g["W"].requires_grad_(True); bias = g["bias"].requires_grad_(True)
+    logits = amd.joint_logits(enc, pred, W, bias)
+    loss = amd.rnnt_loss(logits, g["targets"], g["logit_lens"], g["target_lens"], blank=-1)
+    loss.backward()
+    assert_close_loss("loss", r["loss"], loss.item(), rtol=1e-5)
+    assert_close_grad("grad_enc", r["grad_enc"], enc.grad.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_pred", r["grad_pred"], pred.grad.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_W", r["grad_W"], W.grad.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_bias", r["grad_bias"], bias.grad.cpu().numpy(), rtol=5e-4)
+    amd.engine.release_workspaces()
