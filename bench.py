@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the down-scaled parity twin (keeps rocprof kernel averages clean)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,10 +222,11 @@ def main():
                                 "peak_GBs": PEAK_HBM_GBS, "bytes": sweep_bytes,
                                 "frac": sweep_bytes / (stage_ms["lattice_sweep"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
     if world == 1:
-        try:
-            out["parity"] = parity_twin(H, V, device)
-        except Exception as e:  # noqa: BLE001
-            out["parity"] = {"error": repr(e)}
+        if not args.no_parity:
+            try:
+                out["parity"] = parity_twin(H, V, device)
+            except Exception as e:  # noqa: BLE001
+                out["parity"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             engine.release_workspaces()
             out["cpu_baseline"] = cpu_baseline(T, U, H, V)

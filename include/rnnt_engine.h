@@ -44,6 +44,16 @@ extern "C" {
 /* Library version (RNNT_ENGINE_VERSION it was built with). */
 int rnnt_engine_version(void);
 
+/* Tuning/experiment switches (bit 0: non-temporal logits stores). Returns the old value. */
+int rnnt_engine_set_flags(int flags);
+
+/* Device buffer for diagnostic in-kernel time stamps; only read by builds made with
+ * -DRNNT_STAMPS (never the shipped one). NULL disables. */
+void rnnt_engine_set_debug(void *buf);
+
+/* Diagnostic queries (0/1: predicted resident forward-kernel workgroups per CU). */
+int rnnt_engine_debug_query(int what);
+
 /* Message of the last error on the calling thread ("" if none). */
 const char *rnnt_engine_last_error(void);
 

@@ -14,6 +14,8 @@
 namespace {
 
 thread_local std::string g_err;
+int g_flags = 0;  // experiment switches (rnnt_engine_set_flags)
+unsigned long long *g_debug = nullptr;  // diagnostic stamp buffer (rnnt_engine_set_debug)
 
 int fail(int code, const char *fmt, ...)
 {
@@ -141,7 +143,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         f.wpack = wpack; f.bias = (const float *)bias; f.targets = targets;
         f.logit_lens = logit_lens; f.target_lens = target_lens; f.logits = logits;
         f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
-        f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank;
+        f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = g_flags; f.debug = g_debug;
         launch_joint_fwd(f, st);
     }
     if (stages & ST_LATTICE)
@@ -170,6 +172,12 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
 extern "C" {
 
 int rnnt_engine_version(void) { return RNNT_ENGINE_VERSION; }
+
+int rnnt_engine_set_flags(int flags) { int o = g_flags; g_flags = flags; return o; }
+
+void rnnt_engine_set_debug(void *buf) { g_debug = (unsigned long long *)buf; }
+
+int rnnt_engine_debug_query(int what) { return fwd_occupancy(what); }
 
 const char *rnnt_engine_last_error(void) { return g_err.c_str(); }
 
@@ -233,7 +241,7 @@ int rnnt_engine_joint_fwd(const void *enc, const int64_t enc_strides[3], const v
     memset(&f, 0, sizeof f);
     f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred; f.wpack = wpack;
     f.bias = (const float *)bias; f.logits = (float *)logits;
-    f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = T + U1 - 1; f.blank = V - 1;
+    f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = T + U1 - 1; f.blank = V - 1; f.flags = g_flags; f.debug = g_debug;
     launch_joint_fwd(f, st);
     return launch_status("rnnt_engine_joint_fwd");
 }

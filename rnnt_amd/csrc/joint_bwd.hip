@@ -32,23 +32,17 @@ struct DhFrag {
     f32x4 w[4];  // W rows k0+4*half+s, columns n0+4j..4j+3
 };
 
-__device__ __forceinline__ void dh_load(DhFrag &f, const float *const (&lptr)[2],
-                                        const float *wptr, int k0, int H, int vlim, bool colok)
-{
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const bool vok = k0 < vlim;  // vlim = V - 4*half
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) f.x[mt] = vok ? *(const f32x4 *)(lptr[mt] + k0) : z;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        f.w[s] = (vok && colok) ? *(const f32x4 *)(wptr + (long)(k0 + s) * H) : z;
-}
-
-__device__ __forceinline__ void dh_compute(const DhFrag &f, const CellCoef (&cf)[2], int k0,
-                                           int half, int blank, f32x16 (&acc)[2][4])
+// One 8-wide k chunk (k = vocabulary index): 32 MFMAs.  Same single-buffer rolling refill
+// as the forward kernel: the logits slices of chunk c+1 are requested once G has been
+// generated from chunk c's, and W row s of chunk c+1 right after the 8 MFMAs that read row
+// s of chunk c.  Steady-state loads are unconditional (exact vmcnt counting); the last chunk
+// is peeled.  `kill` zeroes G for lanes whose k range lies beyond V (V % 8 == 4 tail).
+template <bool LAST>
+__device__ __forceinline__ void dh_chunk(DhFrag &f, const CellCoef (&cf)[2], int vb, int blank,
+                                         bool kill, const float *x0n, const float *x1n,
+                                         const float *wn, int H, f32x16 (&acc)[2][4])
 {
     float g[2][4];
-    const int vb = k0 + 4 * half;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int dy = cf[mt].y - vb;
@@ -57,17 +51,25 @@ __device__ __forceinline__ void dh_compute(const DhFrag &f, const CellCoef (&cf)
             float e = __builtin_amdgcn_exp2f(fmaf(f.x[mt][s], RNNT_LOG2E, cf[mt].c1));
             if (dy == s) e -= cf[mt].se;
             if (vb + s == blank) e -= cf[mt].sb;
-            g[mt][s] = e;
+            g[mt][s] = (LAST && kill) ? 0.f : e;
         }
     }
+    if (!LAST) {
+        f.x[0] = *(const f32x4 *)x0n;
+        f.x[1] = *(const f32x4 *)x1n;
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 acc[mt][q] =
                     __builtin_amdgcn_mfma_f32_32x32x2f32(g[mt][s], f.w[s][q], acc[mt][q], 0, 0, 0);
+        if (!LAST) f.w[s] = *(const f32x4 *)(wn + (long)s * H);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // grid (n_ublk, n_ttile, B * n_hblk); 8 waves = 2(M) x 4(N); wave tile 64 cells x 128 cols.
@@ -110,20 +112,33 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
             if (!ok) { cf[mt].c1 = RNNT_NEG_INF; cf[mt].sb = 0.f; cf[mt].se = 0.f; cf[mt].y = -1; }
             lptr[mt] = a.logits + cell * V + 4 * half;
         }
-        const float *wptr = a.W + (long)(4 * half) * H + col;
-        const int vlim = V - 4 * half;
+        // columns beyond H (last column block only) read column 0 instead: their products
+        // land in accumulator columns that are never stored
+        const float *wptr = a.W + (long)(4 * half) * H + (colok ? col : 0);
         const int VK = (V + 7) / 8;
-        DhFrag f0, f1;
-        dh_load(f0, lptr, wptr, 0, H, vlim, colok);
-        for (int c8 = 0; c8 < VK; c8 += 2) {
-            const bool has1 = (c8 + 1) < VK;
-            if (has1) dh_load(f1, lptr, wptr, 8 * (c8 + 1), H, vlim, colok);
-            dh_compute(f0, cf, 8 * c8, half, a.blank, acc);
-            if (has1) {
-                if (c8 + 2 < VK) dh_load(f0, lptr, wptr, 8 * (c8 + 2), H, vlim, colok);
-                dh_compute(f1, cf, 8 * (c8 + 1), half, a.blank, acc);
-            }
+        // V % 8 == 4: in the last chunk lanes 32-63 would read k >= V; step them back 4
+        const bool kill = ((V & 7) != 0) && half == 1;
+        const int back = kill ? 4 : 0;
+        DhFrag f;
+        {
+            const int b0 = (VK == 1) ? back : 0;
+            f.x[0] = *(const f32x4 *)(lptr[0] - b0);
+            f.x[1] = *(const f32x4 *)(lptr[1] - b0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f.w[s] = *(const f32x4 *)(wptr + (long)(s - b0) * H);
         }
+        for (int c8 = 0; c8 + 2 < VK; ++c8) {
+            const int kn = 8 * (c8 + 1);
+            dh_chunk<false>(f, cf, 8 * c8 + 4 * half, a.blank, false, lptr[0] + kn, lptr[1] + kn,
+                            wptr + (long)kn * H, H, acc);
+        }
+        if (VK >= 2) {
+            const int c8 = VK - 2, kn = 8 * (c8 + 1) - back;
+            dh_chunk<false>(f, cf, 8 * c8 + 4 * half, a.blank, false, lptr[0] + kn, lptr[1] + kn,
+                            wptr + (long)kn * H, H, acc);
+        }
+        dh_chunk<true>(f, cf, 8 * (VK - 1) + 4 * half, a.blank, kill, nullptr, nullptr, nullptr, H,
+                       acc);
     }
 
     // ---- epilogue: dPre = dHidden * (1 - tanh^2); reduce over u (dEnc) and over t (dPred)
@@ -240,45 +255,104 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 // ---------------------------------------------------------------------------------------
 // dW split-K GEMM.  grid (n_vblk, n_hblk, n_split); 4 waves = 2(M) x 2(N); wave tile
 // 128 (v) x 128 (h) = 16 accumulator tiles (256 VGPRs, one wave per SIMD).
-struct DwFrag {
-    f32x4 x;   // logits[cell][v0+4i .. +3]
-    f32x4 p;   // pred[b,u][h0+4j .. +3]
+struct DwRaw {
+    f32x4 x;  // logits[cell][v0+4i .. +3]
+    f32x4 p;  // pred[b,u][h0+4j .. +3]
+    f32x4 e;  // enc[b,t][h0+4j .. +3]
     CellCoef c;
+    bool live;  // false for padding k-steps and for the u == U1 half of an odd row
 };
 
-__device__ __forceinline__ void dw_load(DwFrag &f, const float *lrow, const float *prow,
-                                        const CellCoef *crow, int u, int U1, int V, int H,
-                                        bool vok, bool hok)
+// Walks the (b,t) rows of this split, two lattice cells (u, u+1) per k-step, purely with
+// wave-uniform integer selects so that the software-pipelined loop body stays ONE basic
+// block with unconditional loads (exact vmcnt counting).
+struct DwCursor {
+    long bt, step;
+    int b, t, us;
+};
+
+struct DwLane {   // per-lane constants of the issue path
+    int vsafe, hsafe;  // first column of this lane's logits / hidden slice (clamped to 0)
+    int hV, hH, h1;    // half ? V : 0, half ? H : 0, half
+};
+
+__device__ __forceinline__ void dw_issue(DwRaw &r, DwCursor &c, const JointBwdArgs &a,
+                                         const DwLane &ln, long nstep, long bt_last, int SPB)
 {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const bool uok = u < U1;
-    const int uc = uok ? u : U1 - 1;
-    f.x = vok ? *(const f32x4 *)(lrow + (long)uc * V) : z;
-    f.p = hok ? *(const f32x4 *)(prow + (long)uc * H) : z;
-    f.c = crow[uc];
-    if (!uok) { f.c.c1 = RNNT_NEG_INF; f.c.sb = 0.f; f.c.se = 0.f; f.c.y = -1; }
+    const int U1 = a.U1;
+    // lanes 0-31 take cell u = 2*us, lanes 32-63 cell u+1; on the odd tail of a row the upper
+    // half re-reads cell u (valid memory) and is masked through `live`.  All row/step
+    // arithmetic is wave-uniform (SALU); the per-lane part is one select + adds.
+    const bool tail = (2 * c.us + 1) >= U1;
+    const long cell0 = c.bt * U1 + 2 * c.us;
+    const long prow0 = (long)c.b * U1 + 2 * c.us;
+    r.live = (c.step < nstep) && !(tail && ln.h1);
+    r.x = *(const f32x4 *)(a.logits + cell0 * a.V + ((tail ? 0 : ln.hV) + ln.vsafe));
+    r.p = *(const f32x4 *)(a.pred + prow0 * a.H + ((tail ? 0 : ln.hH) + ln.hsafe));
+    r.e = *(const f32x4 *)(a.enc + (long)c.b * a.enc_sb + (long)c.t * a.enc_st + ln.hsafe);
+    r.c = a.coef[cell0 + (tail ? 0 : ln.h1)];
+    // advance (stays on the last row once the split is exhausted: addresses remain valid)
+    c.step += 1;
+    const bool wrap = (c.us + 1) == SPB;
+    const bool adv = wrap && (c.bt < bt_last);
+    c.us = wrap ? 0 : c.us + 1;
+    const bool nb = adv && (c.t + 1 == a.T);
+    c.bt += adv ? 1 : 0;
+    c.t = adv ? (nb ? 0 : c.t + 1) : c.t;
+    c.b += nb ? 1 : 0;
 }
 
-__device__ __forceinline__ void dw_compute(const DwFrag &f, const f32x4 &e4, int vbase, int blank,
-                                           f32x16 (&acc)[4][4], float (&dbacc)[4])
+// One k-step of the software pipeline, written as four sub-blocks so that the VALU work
+// that generates the NEXT step's operands (G = A operand, 4 interleaved v tiles; hidden =
+// B operand, 4 interleaved h tiles) issues in the shadow of the CURRENT step's 16 MFMAs:
+// sub-block q = {generate operand q of step s+1, 4 MFMAs of row q of step s}.  Cells
+// outside the lattice (k_coef marks them with c1 = -inf) contribute exactly 0.
+__device__ __forceinline__ void dw_step(const DwRaw &rn, float (&gN)[4], float (&hN)[4],
+                                        const float (&gC)[4], const float (&hC)[4], int vbase,
+                                        int blank, f32x16 (&acc)[4][4], float (&dbacc)[4])
 {
-    float g[4], hd[4];
-    const int dy = f.c.y - vbase, db = blank - vbase;
+    const bool ok = rn.live && (rn.c.c1 != RNNT_NEG_INF);
+    const float c1 = ok ? rn.c.c1 : RNNT_NEG_INF;
+    const float sb = ok ? rn.c.sb : 0.f, se = ok ? rn.c.se : 0.f;
+    const int dy = rn.c.y - vbase, db = blank - vbase;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float e = __builtin_amdgcn_exp2f(fmaf(f.x[q], RNNT_LOG2E, f.c.c1));
-        if (dy == q) e -= f.c.se;
-        if (db == q) e -= f.c.sb;
-        g[q] = e;
+        const float x = ok ? rn.x[q] : 0.f;  // rows t >= T_b were never written by the forward
+        float e = __builtin_amdgcn_exp2f(fmaf(x, RNNT_LOG2E, c1));
+        if (dy == q) e -= se;
+        if (db == q) e -= sb;
+        gN[q] = e;
         dbacc[q] += e;
-        hd[q] = fast_tanh(e4[q] + f.p[q]);
-    }
-#pragma unroll
-    for (int qm = 0; qm < 4; ++qm)
+        hN[q] = fast_tanh(rn.e[q] + rn.p[q]);
 #pragma unroll
         for (int qn = 0; qn < 4; ++qn)
-            acc[qm][qn] =
-                __builtin_amdgcn_mfma_f32_32x32x2f32(g[qm], hd[qn], acc[qm][qn], 0, 0, 0);
+            acc[q][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(gC[q], hC[qn], acc[q][qn], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // 5 VALU in its shadow
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void dw_gen_first(const DwRaw &r, int vbase, int blank, float (&g)[4],
+                                             float (&hd)[4], float (&dbacc)[4])
+{
+    const bool ok = r.live && (r.c.c1 != RNNT_NEG_INF);
+    const float c1 = ok ? r.c.c1 : RNNT_NEG_INF;
+    const float sb = ok ? r.c.sb : 0.f, se = ok ? r.c.se : 0.f;
+    const int dy = r.c.y - vbase, db = blank - vbase;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x = ok ? r.x[q] : 0.f;
+        float e = __builtin_amdgcn_exp2f(fmaf(x, RNNT_LOG2E, c1));
+        if (dy == q) e -= se;
+        if (db == q) e -= sb;
+        g[q] = e;
+        dbacc[q] += e;
+        hd[q] = fast_tanh(r.e[q] + r.p[q]);
+    }
 }
 
 __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
@@ -304,27 +378,43 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (v0 < V && h0 < H) {  // wave-uniform
-        for (long bt = bt_lo; bt < bt_hi; ++bt) {
-            const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
-            if (t >= a.logit_lens[b]) continue;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 e4 =
-                hok ? *(const f32x4 *)(a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + hbase) : z;
-            const float *lrow = a.logits + bt * U1 * V + (vok ? vbase : 0);
-            const float *prow = a.pred + (long)b * U1 * H + (hok ? hbase : 0);
-            const CellCoef *crow = a.coef + bt * U1;
-            DwFrag f0, f1;
-            dw_load(f0, lrow, prow, crow, half, U1, V, H, vok, hok);
-            for (int u = 0; u < U1; u += 4) {
-                const bool has1 = (u + 2) < U1;
-                if (has1) dw_load(f1, lrow, prow, crow, u + 2 + half, U1, V, H, vok, hok);
-                dw_compute(f0, e4, vbase, a.blank, acc, dbacc);
-                if (has1) {
-                    if (u + 4 < U1) dw_load(f0, lrow, prow, crow, u + 4 + half, U1, V, H, vok, hok);
-                    dw_compute(f1, e4, vbase, a.blank, acc, dbacc);
-                }
-            }
+    if (v0 < V && h0 < H && bt_hi > bt_lo) {  // wave-uniform
+        const int SPB = (U1 + 1) / 2;
+        const long nstep = (bt_hi - bt_lo) * SPB;
+        // rows / columns beyond V / H (edge tiles) read row/column 0: their results sit in
+        // accumulator rows / columns that are never stored
+        DwLane ln;
+        ln.vsafe = vok ? vbase : 0; ln.hsafe = hok ? hbase : 0;
+        ln.hV = half ? V : 0; ln.hH = half ? H : 0; ln.h1 = half;
+        DwCursor cur;
+        cur.bt = bt_lo; cur.step = 0; cur.us = 0;
+        cur.b = (int)(bt_lo / T); cur.t = (int)(bt_lo - (long)cur.b * T);
+        const long bt_last = bt_hi - 1;
+        DwRaw r0, r1, r2, r3;
+        float gA[4], hA[4], gB[4], hB[4];
+        // 4 raw k-steps in flight (~4 x 1024 matrix-pipe cycles of lead for the HBM-streamed
+        // logits); operands of step s+1 are generated while the 16 MFMAs of step s issue.
+        dw_issue(r0, cur, a, ln, nstep, bt_last, SPB);
+        dw_issue(r1, cur, a, ln, nstep, bt_last, SPB);
+        dw_issue(r2, cur, a, ln, nstep, bt_last, SPB);
+        dw_issue(r3, cur, a, ln, nstep, bt_last, SPB);
+        dw_gen_first(r0, vbase, a.blank, gA, hA, dbacc);
+        dw_issue(r0, cur, a, ln, nstep, bt_last, SPB);
+        __builtin_amdgcn_sched_barrier(0);
+        for (long s = 0; s < nstep; s += 4) {
+            // at the top: (gA,hA) = operands of step s; r1..r3,r0 hold raw steps s+1..s+4
+            dw_step(r1, gB, hB, gA, hA, vbase, a.blank, acc, dbacc);
+            dw_issue(r1, cur, a, ln, nstep, bt_last, SPB);
+            __builtin_amdgcn_sched_barrier(0);
+            dw_step(r2, gA, hA, gB, hB, vbase, a.blank, acc, dbacc);
+            dw_issue(r2, cur, a, ln, nstep, bt_last, SPB);
+            __builtin_amdgcn_sched_barrier(0);
+            dw_step(r3, gB, hB, gA, hA, vbase, a.blank, acc, dbacc);
+            dw_issue(r3, cur, a, ln, nstep, bt_last, SPB);
+            __builtin_amdgcn_sched_barrier(0);
+            dw_step(r0, gA, hA, gB, hB, vbase, a.blank, acc, dbacc);
+            dw_issue(r0, cur, a, ln, nstep, bt_last, SPB);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

@@ -24,7 +24,9 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#define FWD_ROWS 128
+#define FWD_MWAVES 4  // 8 waves = 4 (M) x 2 (N): two waves per SIMD
+#define FWD_ROWS (32 * FWD_MWAVES)
+#define FWD_THREADS (128 * FWD_MWAVES)
 
 size_t wpack_floats(int H, int V)
 {
@@ -87,51 +89,158 @@ void launch_copy_enc(const float *enc, long sb, long st_, long sh, float *dst, i
                        st_, sh, dst, B, T, H);
 }
 
-struct FwdFrag {
-    f32x4 e, p;
+#define FWD_NBUF 4         // LDS ring of B chunks
+#define FWD_BCHUNK 1024    // float4 per staged chunk: 512 columns x 8 k
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+
+// Register-destination loads that hipcc must NOT see: next to an LDS-DMA in flight it would
+// guard their first use with s_waitcnt vmcnt(0) and drain the DMA ring every chunk.  The
+// destinations are only read after vm_wait<N>(), which names them as in/out operands so no
+// consumer can be scheduled above the wait (cdna_hip_programming.md §5.7, form (ii)).
+__device__ __forceinline__ void asm_load16(f32x4 &dst, const float *ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(f32x4 &e, f32x4 &p)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e), "+v"(p) : "n"(N) : "memory");
+}
+
+// Main loop over H in 8-wide chunks: 32 MFMAs per wave and chunk (8 accumulator tiles x 4
+// k-steps); the workgroup's 8 waves = 4 (M) x 2 (N) cover 128 cells x 512 columns.
+//
+// What was measured before this design (tools/mfma_mix2.hip, s_memtime stamps in the kernel):
+//  * the SIMD arbitrates oldest-first: unsynchronised, the older of the two waves sharing a
+//    SIMD runs a whole pass ahead and the younger one finishes alone, bubbles unfilled;
+//  * vmcnt retires in order: one young load that is waited for (the A slices) drags every
+//    older B-fragment load with it, and B fragments streamed from L2 cost ~8 % even alone.
+// Hence:
+//  * B (W) chunks go global -> LDS by LDS-DMA (global_load_lds, no VGPRs), FWD_NBUF-deep ring,
+//    issued two chunks ahead; fragments are then read LDS -> VGPR (ds_read_b128, its own
+//    lgkmcnt counter, short fixed latency) right after the 4 MFMAs that used the previous one;
+//  * the only register-destination VMEM loads are the A slices (enc/pred), issued right after
+//    tanh consumed the previous ones and BEFORE the chunk's DMA, so `vmcnt(2)` at the top of
+//    the next chunk retires them and the 2-chunk-old DMA but leaves the newest DMA in flight;
+//  * tanh for chunk c+1 is computed one element per MFMA group while chunk c's MFMAs issue;
+//  * one s_barrier per chunk publishes the ring slot and keeps the SIMD partners in step.
+// Chunk order is rotated per workgroup (`rot`; the k-order of a dot product is free) so the
+// CUs do not all walk the same 16 KB of wpack at once.  W is zero-padded in wpack, tanh of any
+// finite input is finite, and address clamps keep every load in bounds, so no load in the
+// loop is conditional.
+__device__ __forceinline__ void fwd_mainloop(const float *erow, const float *prow,
+                                             const f32x4 *wpass, int gvalid, int HK,
+                                             long wstride, int H, int half, int rot, int wave,
+                                             int lane, int wn, f32x4 *ldsb, f32x16 (&acc)[8])
+{
+    // H % 8 == 4: in the last chunk lanes 32-63 would read k >= H; step them back 4 floats
+    // (their B values are zero in wpack, so whatever finite A they form contributes 0)
+    const int back = (((H & 7) != 0) && half == 1) ? 4 : 0;
+    const int last = HK - 1;
+    auto nextc = [&](int cc) { return cc + 1 >= HK ? 0 : cc + 1; };
+    auto aoff = [&](int cc) { return 8 * cc - (cc == last ? back : 0); };
+    // this wave's share of a chunk's DMA: float4 [wave*128, +128) of the 1024; column groups
+    // beyond the last valid one of a partial pass re-read group 0 (their tiles are discarded)
+    const int dgrp = wave >> 1;
+    const int dsrc = (dgrp < gvalid ? wave * 128 : (wave & 1) * 128) + lane;
+    auto dma = [&](int cc, int slot) {
+        const f32x4 *src = wpass + (long)cc * wstride + dsrc;
+        f32x4 *dst = ldsb + slot * FWD_BCHUNK + wave * 128;  // wave-uniform (goes to M0)
+        __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 64, (lds_void_ptr)(dst + 64), 16, 0, 0);
+    };
+    const int roff = wn * 512 + lane;  // this wave's first fragment inside a staged chunk
+
     f32x4 w[8];
-};
-
-__device__ __forceinline__ void fwd_load_a(FwdFrag &f, const float *erow, const float *prow,
-                                           int c8, bool koob, int hlim)
-{
-    const int k = 8 * c8;
-    const bool ok = !koob || (k < hlim);  // hlim = H - 4*half
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f.e = ok ? *(const f32x4 *)(erow + k) : z;
-    f.p = ok ? *(const f32x4 *)(prow + k) : z;
-}
-
-// One 8-wide k chunk: 32 MFMAs.  Operands are single-buffered with a rolling refill: the
-// enc/pred slices of chunk c8+1 are requested as soon as tanh has consumed chunk c8's, and
-// B fragment q of chunk c8+1 is requested right after the 4 MFMAs that read fragment q of
-// chunk c8 — each request then has >= 28 MFMAs (~1800 cycles) of matrix work in front of
-// its first use, without a second register set.
-template <bool G1>
-__device__ __forceinline__ void fwd_chunk(FwdFrag &f, const float *erow, const float *prow,
-                                          const f32x4 *wp, int c8, int HK, long wstride,
-                                          bool koob, int hlim, f32x16 (&acc)[8])
-{
-    float a[4];
+    float a_cur[4], a_nxt[4];
+    int cc = rot;              // chunk of step 0
+    int c1 = nextc(cc), c2 = nextc(c1);
+    dma(cc, 0);
+    dma(c1, 1);
+    f32x4 e, p;
+    asm_load16(e, erow + aoff(cc));
+    asm_load16(p, prow + aoff(cc));
+    vm_wait<0>(e, p);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = fast_tanh(f.e[s] + f.p[s]);
-    const bool more = (c8 + 1) < HK;
-    if (more) fwd_load_a(f, erow, prow, c8 + 1, koob, hlim);
-    const f32x4 *wn = wp + (long)(c8 + 1) * wstride;
+    for (int q = 0; q < 8; ++q) w[q] = ldsb[roff + q * 64];
 #pragma unroll
-    for (int q = 0; q < (G1 ? 8 : 4); ++q) {
+    for (int s = 0; s < 4; ++s) a_cur[s] = fast_tanh(e[s] + p[s]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm_load16(e, erow + aoff(c1));
+    asm_load16(p, prow + aoff(c1));
+    __builtin_amdgcn_sched_barrier(0);
+    dma(c2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    int cdma = nextc(c2);  // chunk the next DMA fetches (step c8+3)
+    int ca = c2;           // chunk whose raw A is fetched next (step c8+2)
+    int slot_rd = 1, slot_wr = 3;
+    for (int c8 = 0; c8 < HK; ++c8) {
+        // retire this wave's A slices and its share of the DMA issued two chunks ago (step
+        // c8+1's B); the newest DMA (2 ops) stays in flight across the barrier
+        vm_wait<2>(e, p);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 *rd = ldsb + slot_rd * FWD_BCHUNK + roff;
+        const int a2 = aoff(ca);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], f.w[q][s], acc[q], 0, 0, 0);
-        if (more) f.w[q] = wn[q * 64];
+        for (int q = 0; q < 8; ++q) {
+            if (q < 4) a_nxt[q] = fast_tanh(e[q] + p[q]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], w[q][s], acc[q], 0, 0, 0);
+            w[q] = rd[q * 64];
+            if (q == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm_load16(e, erow + a2);
+                asm_load16(p, prow + a2);
+                __builtin_amdgcn_sched_barrier(0);
+                dma(cdma, slot_wr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
+        ca = nextc(ca);
+        cdma = nextc(cdma);
+        slot_rd = (slot_rd + 1) & (FWD_NBUF - 1);
+        slot_wr = (slot_wr + 1) & (FWD_NBUF - 1);
     }
+    // drain the DMA that ran ahead past the last step before the ring is reused / the
+    // workgroup exits, and make sure every wave is done reading
+    vm_wait<0>(e, p);
+    __builtin_amdgcn_s_barrier();
 }
+
+#ifdef RNNT_STAMPS
+// Diagnostic build only (make EXTRA=-DRNNT_STAMPS): per-workgroup s_memtime stamps written to a
+// debug buffer no kernel reads; never enabled in the shipped library.
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        if (a.debug && tid == 0) {                                                           \
+            unsigned long long t_;                                                           \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (slot)] = t_;          \
+        }                                                                                    \
+    } while (0)
+#else
+#define STAMP(slot)
+#endif
 
 template <bool WITH_LOSS>
-__global__ __launch_bounds__(512, 2) void k_joint_fwd(JointFwdArgs a)
+__global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
 {
-    __shared__ float s_m[2][FWD_ROWS], s_s[2][FWD_ROWS], s_blank[FWD_ROWS], s_emit[FWD_ROWS];
-    __shared__ int s_y[FWD_ROWS];
+    // ALL LDS in one array (hipcc otherwise guards every ds_read with vmcnt(0) while an LDS-DMA
+    // is in flight): [B ring | per-lane running softmax state | per-row (max,sum) of 2 N-waves]
+    __shared__ __attribute__((aligned(16))) char smem[FWD_NBUF * FWD_BCHUNK * 16 +
+                                                      16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4];
+    f32x4 *s_b = (f32x4 *)smem;
+    float2(*s_run2)[FWD_THREADS] = (float2(*)[FWD_THREADS])(smem + FWD_NBUF * FWD_BCHUNK * 16);
+    float(*s_m)[FWD_ROWS] =
+        (float(*)[FWD_ROWS])(smem + FWD_NBUF * FWD_BCHUNK * 16 + 16 * FWD_THREADS * 8);
+    float(*s_s)[FWD_ROWS] = s_m + 2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -142,22 +251,27 @@ __global__ __launch_bounds__(512, 2) void k_joint_fwd(JointFwdArgs a)
     const int Tb = WITH_LOSS ? a.logit_lens[b] : T;
     const int ncell = Tb * U1;
     if (m0 >= ncell) return;
+    STAMP(0);
+#ifdef RNNT_STAMPS
+    if (a.debug && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 8 + wave] =
+            ((unsigned long long)xcc << 32) | hw;
+        if (wave == 0)
+            a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 7] =
+                ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int Ub = WITH_LOSS ? a.target_lens[b] : U1 - 1;
 
+    // per-lane running (max, sum-exp) of the 16 accumulator rows this lane sees, parked in LDS
+    // between passes (slot [r][tid]: conflict-free) so it costs no VGPRs in the main loop;
+    // folded in-lane after every pass and combined across lanes only once per tile.
     if (WITH_LOSS) {
-        if (tid < FWD_ROWS) {
-            const int c = m0 + tid;
-            int y = -1;
-            if (c < ncell) {
-                const int t = c / U1, u = c - t * U1;
-                if (u < Ub) y = a.targets[(long)b * (U1 - 1) + u];
-            }
-            s_y[tid] = y;
-            s_m[0][tid] = RNNT_NEG_INF; s_m[1][tid] = RNNT_NEG_INF;
-            s_s[0][tid] = 0.f; s_s[1][tid] = 0.f;
-            s_blank[tid] = 0.f; s_emit[tid] = 0.f;
-        }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_run2[r][tid] = make_float2(RNNT_NEG_INF, 0.f);
     }
 
     // this lane's A row: cell -> (t,u) -> 16-byte slices of enc / pred
@@ -167,16 +281,15 @@ __global__ __launch_bounds__(512, 2) void k_joint_fwd(JointFwdArgs a)
     const float *prow = a.pred + ((long)b * U1 + urow) * H + 4 * half;
     const int HK = (H + 7) / 8, NG = (V + 127) / 128;
     const long wstride = (long)NG * 256;  // float4 per 8-wide k chunk
-    const bool koob = (H & 7) != 0;
-    const int hlim = H - 4 * half;
     const int npass = (NG + 3) / 4;
+
+    const int rot = (int)(((unsigned)blockIdx.x * 5u + (unsigned)blockIdx.y * 11u) % (unsigned)HK);
 
     for (int pass = 0; pass < npass; ++pass) {
         const int ng0 = pass * 4 + wn * 2;
-        if (ng0 >= NG) continue;  // wave-uniform: no columns for this wave in this pass
-        const bool g1 = (ng0 + 1) < NG;
+        const bool g0 = ng0 < NG, g1 = (ng0 + 1) < NG;
         const int col0[2] = {ng0 * 128 + 4 * i, (ng0 + 1) * 128 + 4 * i};
-        const bool cok[2] = {col0[0] < V, g1 && col0[1] < V};
+        const bool cok[2] = {g0 && col0[0] < V, g1 && col0[1] < V};
 
         f32x16 acc[8];
 #pragma unroll
@@ -189,21 +302,11 @@ __global__ __launch_bounds__(512, 2) void k_joint_fwd(JointFwdArgs a)
                 for (int r = 0; r < 16; ++r) acc[g * 4 + q][r] = bq[q];
         }
 
-        const f32x4 *wp = (const f32x4 *)a.wpack + (long)ng0 * 256 + lane;
-        FwdFrag f;
-        fwd_load_a(f, erow, prow, 0, koob, hlim);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f.w[q] = (q < 4 || g1) ? wp[q * 64] : z;
-        }
-        if (g1) {
-            for (int c8 = 0; c8 < HK; ++c8)
-                fwd_chunk<true>(f, erow, prow, wp, c8, HK, wstride, koob, hlim, acc);
-        } else {
-            for (int c8 = 0; c8 < HK; ++c8)
-                fwd_chunk<false>(f, erow, prow, wp, c8, HK, wstride, koob, hlim, acc);
-        }
+        const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
+        const int gvalid = min(4, NG - pass * 4);
+        STAMP(1 + 2 * (pass & 1));
+        fwd_mainloop(erow, prow, wpass, gvalid, HK, wstride, H, half, rot, wave, lane, wn, s_b, acc);
+        STAMP(2 + 2 * (pass & 1));
 
         // ---- epilogue: store logits, fold this pass into the running row log-sum-exp
 #pragma unroll
@@ -217,72 +320,110 @@ __global__ __launch_bounds__(512, 2) void k_joint_fwd(JointFwdArgs a)
                 if (rv && cok[g]) {
                     f32x4 o = {acc[g * 4 + 0][r], acc[g * 4 + 1][r], acc[g * 4 + 2][r],
                                acc[g * 4 + 3][r]};
-                    *(f32x4 *)(lrow + col0[g]) = o;
+                    if (a.flags & 1)
+                        __builtin_nontemporal_store(o, (f32x4 *)(lrow + col0[g]));
+                    else
+                        *(f32x4 *)(lrow + col0[g]) = o;
                 }
-            if (WITH_LOSS) {
-                float mloc = RNNT_NEG_INF;
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (cok[g]) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) mloc = fmaxf(mloc, acc[g * 4 + q][r]);
-                    }
-                const float mrow = half_max(mloc);
-                float sloc = 0.f;
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (cok[g]) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) sloc += __expf(acc[g * 4 + q][r] - mrow);
-                    }
-                const float srow = half_sum(sloc);
-                const int y = s_y[rowl];
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (cok[g]) {
-                        const int dy = y - col0[g], db = a.blank - col0[g];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (dy == q) s_emit[rowl] = acc[g * 4 + q][r];
-                            if (db == q) s_blank[rowl] = acc[g * 4 + q][r];
-                        }
-                    }
-                if (i == 0) {
-                    const float mo = s_m[wn][rowl], so = s_s[wn][rowl];
-                    const float mn = fmaxf(mo, mrow);
-                    s_s[wn][rowl] = so * __expf(mo - mn) + srow * __expf(mrow - mn);
-                    s_m[wn][rowl] = mn;
-                }
+            if (WITH_LOSS && cok[0]) {  // cok[1] implies cok[0]
+                float ml = fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[2][r], acc[3][r]));
+                if (cok[1])
+                    ml = fmaxf(ml, fmaxf(fmaxf(acc[4][r], acc[5][r]), fmaxf(acc[6][r], acc[7][r])));
+                const float2 ms = s_run2[r][tid];
+                const float mn = fmaxf(ms.x, ml);
+                float sl = __expf(acc[0][r] - mn) + __expf(acc[1][r] - mn) +
+                           __expf(acc[2][r] - mn) + __expf(acc[3][r] - mn);
+                if (cok[1])
+                    sl += __expf(acc[4][r] - mn) + __expf(acc[5][r] - mn) +
+                          __expf(acc[6][r] - mn) + __expf(acc[7][r] - mn);
+                // exp(-inf - finite) = 0 on the first pass
+                s_run2[r][tid] = make_float2(mn, ms.y * __expf(ms.x - mn) + sl);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the 16 row bodies from interleaving
         }
     }
 
+    STAMP(5);
+#ifdef RNNT_STAMPS
+    if (a.debug && lane == 0) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + wave] = t_;
+    }
+#endif
     if (WITH_LOSS) {
-        __syncthreads();
+        // ---- once per tile: combine the 32 lanes that share a row, then the two N-waves
+        float m_run[16], s_run[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float2 ms = s_run2[r][tid];
+            m_run[r] = ms.x; s_run[r] = ms.y;
+        }
+#pragma unroll
+        for (int k = 16; k >= 1; k >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float mo = __shfl_xor(m_run[r], k, 64), so = __shfl_xor(s_run[r], k, 64);
+                const float mn = fmaxf(m_run[r], mo);
+                const float e1 = (m_run[r] == RNNT_NEG_INF) ? 0.f : __expf(m_run[r] - mn);
+                const float e2 = (mo == RNNT_NEG_INF) ? 0.f : __expf(mo - mn);
+                s_run[r] = s_run[r] * e1 + so * e2;
+                m_run[r] = mn;
+            }
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                s_m[wn][rowl] = m_run[r];
+                s_s[wn][rowl] = s_run[r];
+            }
+        }
+        __syncthreads();  // also drains this workgroup's logits stores (vmcnt(0))
         if (tid < FWD_ROWS) {
             const int c = m0 + tid;
             if (c < ncell) {
                 const int t = c / U1, u = c - t * U1;
                 const float ma = s_m[0][tid], mb = s_m[1][tid];
                 const float m = fmaxf(ma, mb);
-                const float s = s_s[0][tid] * __expf(ma - m) + s_s[1][tid] * __expf(mb - m);
-                const float den = m + logf(s);
+                const float ea = (ma == RNNT_NEG_INF) ? 0.f : __expf(ma - m);
+                const float eb = (mb == RNNT_NEG_INF) ? 0.f : __expf(mb - m);
+                const float den = m + logf(s_s[0][tid] * ea + s_s[1][tid] * eb);
+                // the two logits the lattice needs were stored by this workgroup a moment ago:
+                // read them back from L2 (agent-scope loads bypass the CU's vector L1)
+                const float *lrow = a.logits + ((long)b * T * U1 + c) * V;
+                const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                const int y = (u < Ub) ? a.targets[(long)b * (U1 - 1) + u] : -1;
+                const float le = (y >= 0) ? __hip_atomic_load(lrow + y, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT)
+                                          : den;
                 const long si = skew_index(b, t, u, a.D, U1);
                 a.denom_s[si] = den;
-                a.lpb_s[si] = s_blank[tid] - den;
-                a.lpe_s[si] = (s_y[tid] >= 0) ? s_emit[tid] - den : 0.f;
+                a.lpb_s[si] = lb - den;
+                a.lpe_s[si] = le - den;
             }
         }
     }
+    STAMP(6);
 }
 
 void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
 {
     const int tiles = (int)(((long)a.T * a.U1 + FWD_ROWS - 1) / FWD_ROWS);
-    dim3 grid(tiles, a.B), block(512);
+    dim3 grid(tiles, a.B), block(FWD_THREADS);
     if (a.denom_s)
         hipLaunchKernelGGL(k_joint_fwd<true>, grid, block, 0, st, a);
     else
         hipLaunchKernelGGL(k_joint_fwd<false>, grid, block, 0, st, a);
+}
+
+// Diagnostic: resident workgroups per CU the runtime predicts for the forward kernel.
+int fwd_occupancy(int with_loss)
+{
+    int n = -1;
+    if (with_loss)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_joint_fwd<true>, FWD_THREADS, 0);
+    else
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_joint_fwd<false>, FWD_THREADS, 0);
+    return n;
 }

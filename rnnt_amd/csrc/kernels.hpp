@@ -28,10 +28,13 @@ struct JointFwdArgs {
     float *logits;      // [B,T,U1,V]
     float *denom_s, *lpb_s, *lpe_s;  // skewed [B,D,U1]; NULL for the plain joint
     int B, T, U1, H, V, D, blank;
+    int flags;  // bit0: non-temporal logits stores
+    unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
 };
 size_t wpack_floats(int H, int V);
 void launch_pack_w_fwd(const float *W, float *wpack, int H, int V, hipStream_t st);
 void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st);
+int fwd_occupancy(int with_loss);
 void launch_copy_enc(const float *enc, long sb, long st_, long sh, float *dst, int B, int T, int H,
                      hipStream_t st);
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ double logaddexp_mixed(double a, double e)
 // not depend on the recurrence.  DIR 0: alpha, forward over d = 0..nd-1.  DIR 1: beta,
 // backward; also emits costs[b] = -beta[0,0].
 template <int DIR>
-__global__ __launch_bounds__(1024) void k_lattice(
+__device__ __forceinline__ void lattice_sweep(
     const float *__restrict__ lpb_s, const float *__restrict__ lpe_s,
     double *__restrict__ out_s, const int32_t *__restrict__ logit_lens,
     const int32_t *__restrict__ target_lens, float *__restrict__ costs, int U1, int D)
@@ -250,15 +250,27 @@ void launch_logsoftmax_gather(const float *logits, const int32_t *targets,
                        V, D, blank);
 }
 
+// grid (B, 2): blockIdx.y selects the direction, so the 2B independent sweeps of a batch
+// run concurrently on 2B compute units in ONE launch.
+__global__ __launch_bounds__(1024) void k_lattice(
+    const float *__restrict__ lpb_s, const float *__restrict__ lpe_s,
+    double *__restrict__ alpha_s, double *__restrict__ beta_s,
+    const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
+    float *__restrict__ costs, int U1, int D)
+{
+    if (blockIdx.y == 0)
+        lattice_sweep<0>(lpb_s, lpe_s, alpha_s, logit_lens, target_lens, costs, U1, D);
+    else
+        lattice_sweep<1>(lpb_s, lpe_s, beta_s, logit_lens, target_lens, costs, U1, D);
+}
+
 void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, double *beta_s,
                     const int32_t *logit_lens, const int32_t *target_lens, float *costs, int B,
                     int U1, int D, hipStream_t st)
 {
     const int NT = ((U1 + 63) / 64) * 64;
     const size_t lds = 2 * (size_t)(NT + 2) * sizeof(double);
-    hipLaunchKernelGGL(k_lattice<0>, dim3(B), dim3(NT), lds, st, lpb_s, lpe_s, alpha_s,
-                       logit_lens, target_lens, costs, U1, D);
-    hipLaunchKernelGGL(k_lattice<1>, dim3(B), dim3(NT), lds, st, lpb_s, lpe_s, beta_s,
+    hipLaunchKernelGGL(k_lattice, dim3(B, 2), dim3(NT), lds, st, lpb_s, lpe_s, alpha_s, beta_s,
                        logit_lens, target_lens, costs, U1, D);
 }
 

@@ -1,0 +1,28 @@
+"""Experiment: time the plain joint forward (no softmax epilogue) vs fused stage 0 at cfg2."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synth
+from rnnt_amd import engine
+B, T, U, H, V = 32, 1000, 200, 512, 1024
+enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
+def timeit(f, n=3):
+    f(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n
+outs = engine.alloc_fused_outputs(enc, pred, W)
+print("fused stage0 (with softmax epilogue) ms:", timeit(lambda: engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V-1, 1/B, outs=outs, stage=0)))
+engine.release_workspaces()
+import ctypes
+logits = torch.empty((B, T, U+1, V), device="cuda")
+n = ctypes.c_size_t(0)
+engine.lib().rnnt_engine_joint_fwd_workspace_bytes(B, T, U+1, H, V, 0, ctypes.byref(n))
+ws = engine.workspace(enc.device, n.value)
+def plain():
+    engine._check(engine.lib().rnnt_engine_joint_fwd(engine._p(enc), engine._strides3(enc), engine._p(pred), engine._p(W), engine._p(bias), B, T, U+1, H, V, 0, engine._p(logits), engine._p(ws), ctypes.c_size_t(ws.numel()), engine._stream(enc.device)))
+print("plain joint_fwd (stores only) ms:", timeit(plain))
+engine.lib().rnnt_engine_set_flags(1)
+print("plain joint_fwd, nt stores ms:", timeit(plain))

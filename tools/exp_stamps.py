@@ -1,0 +1,46 @@
+"""Diagnostic: per-workgroup phase timing of k_joint_fwd from s_memtime stamps (RNNT_STAMPS build)."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bench import synth
+from rnnt_amd import engine
+B, T, U, H, V = 32, 1000, 200, 512, 1024
+enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
+outs = engine.alloc_fused_outputs(enc, pred, W)
+run = lambda: engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V-1, 1/B, outs=outs, stage=0)
+run(); torch.cuda.synchronize()
+ROWS = int(os.environ.get("FWD_ROWS", "64"))
+ntile = (T*(U+1) + ROWS - 1)//ROWS
+dbg = torch.zeros(B*ntile*32, dtype=torch.int64, device="cuda")
+engine.lib().rnnt_engine_set_debug(ctypes.c_void_p(dbg.data_ptr()))
+run(); torch.cuda.synchronize()
+engine.lib().rnnt_engine_set_debug(ctypes.c_void_p(0))
+d = dbg.cpu().numpy().reshape(-1, 32).astype(np.int64)
+for j in (0, 1, 5000):
+    print('block', j, 'simd of waves 0..7:', [int((x >> 4) & 3) for x in d[j, 8:16]], 'wave slots:', [int(x & 0xf) for x in d[j, 8:16]])
+d = d[d[:,0] != 0]
+wend = d[:, 16:24] - d[:, 0:1]
+print('per-wave end-of-passes time (cycles since WG start), median over WGs, waves 0..7:', np.median(wend[d[:,0]!=0], axis=0).astype(int))
+names = ["prologue(0->1)", "main p0(1->2)", "epi p0(2->3)", "main p1(3->4)", "epi p1(4->5)", "final(5->6)"]
+print("workgroups stamped:", len(d), " ideal mainloop cycles per pass (2 waves/SIMD):", 64*32*64*2, " s_memtime ticks are 100MHz? check ratio")
+for i, n in enumerate(names):
+    x = d[:, i+1] - d[:, i]
+    print(f"{n:18s} median {np.median(x):10.0f}  p10 {np.percentile(x,10):10.0f}  p90 {np.percentile(x,90):10.0f}")
+tot = d[:,6]-d[:,0]
+print("total per WG median", np.median(tot), " kernel span", d[:,6].max()-d[:,0].min())
+# concurrency: how many WG start times are within a small window -> lockstep?
+st = np.sort(d[:,0]); print("start-time gaps: median", np.median(np.diff(st)))
+# ---- residency census: per (xcc, se, sh, cu) count overlapping workgroups over time
+hw = d[:, 7]
+xcc = (hw >> 32) & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4) & 3; wv = hw & 0xf
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+print("distinct CUs seen:", len(np.unique(key)), " distinct xcc:", np.unique(xcc), " simd of wave0:", np.bincount(simd), " wave slot ids:", np.bincount(wv))
+ov = []
+for k in np.unique(key)[:64]:
+    m = key == k
+    st, en = d[m, 0], d[m, 6]
+    order = np.argsort(st); st, en = st[order], en[order]
+    cnt = [(en[:i] > st[i]).sum() + 1 for i in range(1, len(st))]
+    ov.append(np.mean(cnt))
+print("mean number of co-resident workgroups on a CU at workgroup start (first 64 CUs):", np.mean(ov), " min", np.min(ov), " max", np.max(ov))
