@@ -120,8 +120,8 @@ int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3]
  * inspect single stages; not needed by training code.
  */
 typedef struct rnnt_engine_ws_layout {
-    size_t logits, denom_s, lpb_s, lpe_s, alpha_s, beta_s, coef, wpack, enc_copy;
-    size_t slab_enc, slab_pred, slab_w, slab_b, total;
+    size_t logits, hidden, denom_s, lpb_s, lpe_s, alpha_s, beta_s, coef, wpack, enc_copy;
+    size_t slab_enc, slab_pred, slab_w, slab_b, total, rows_pad;
     int n_ublk, n_ttile, n_split, D;
 } rnnt_engine_ws_layout;
 
@@ -132,7 +132,7 @@ int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,
  * Run ONE stage of the fused pipeline on an already laid-out workspace (bench/profiling
  * aid: lets bench.py time the dominant kernels with HIP events on the launch stream).
  * stage: 0 pack+joint-forward GEMM, 1 lattice sweep (alpha & beta), 2 gradient
- * coefficients, 3 dHidden GEMM + dEnc/dPred reduction, 4 dW GEMM + dW/db reduction.
+ * coefficients + operand producers (hidden, G in place of logits), 3 dHidden GEMM + dEnc/dPred reduction, 4 dW GEMM + dW/db reduction.
  * Arguments as for rnnt_engine_joint_loss_fwd_bwd.
  */
 int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[3],

@@ -56,12 +56,16 @@ void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
 {
     const size_t D = (size_t)T + U1 - 1;
     const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
+    // G / hidden rows are padded with >= 1 zero row up to a multiple of 16 (dW chunk size)
+    const size_t rows_pad = (cells + 1 + 15) / 16 * 16;
+    L->rows_pad = rows_pad;
     L->D = (int)D;
     L->n_ublk = (U1 + 15) / 16;
     L->n_ttile = (T + 7) / 8;
     L->n_split = dw_splits(B, T, H, V);
     size_t o = 0;
-    L->logits = o;   o += align_up(cells * V * 4);
+    L->logits = o;   o += align_up(rows_pad * V * 4);
+    L->hidden = o;   o += align_up(rows_pad * H * 4);
     L->denom_s = o;  o += align_up(skew * 4);
     L->lpb_s = o;    o += align_up(skew * 4);
     L->lpe_s = o;    o += align_up(skew * 4);
@@ -151,16 +155,21 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     if (stages & ST_COEF)
         launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                     B, T, U1, L.D, grad_scale, st);
-    if (stages & (ST_DH | ST_DW)) {
+    if (stages & (ST_COEF | ST_DH | ST_DW)) {
         JointBwdArgs g;
         g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred;
         g.W = (const float *)W; g.logits = logits; g.coef = coef; g.logit_lens = logit_lens;
+        g.hidden = (float *)(ws + L.hidden); g.rows_pad = (long)L.rows_pad;
         g.slab_enc = (float *)(ws + L.slab_enc); g.slab_pred = (float *)(ws + L.slab_pred);
         g.slab_w = (float *)(ws + L.slab_w); g.slab_b = (float *)(ws + L.slab_b);
         g.grad_enc = (float *)grad_enc; g.grad_pred = (float *)grad_pred;
         g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
         g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
         g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
+        if (stages & ST_COEF) {  // operand producers of the two backward GEMMs
+            launch_make_hidden(g, st);
+            launch_make_g(g, st);
+        }
         if (stages & ST_DH) launch_dhidden(g, st);
         if (stages & ST_DW) launch_dw(g, st);
     }

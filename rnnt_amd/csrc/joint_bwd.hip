@@ -24,58 +24,31 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+
 #define DH_BT 8
 #define DH_BU 16
 
-struct DhFrag {
-    f32x4 x[2];  // logits slices for the two M tiles
-    f32x4 w[4];  // W rows k0+4*half+s, columns n0+4j..4j+3
-};
+#define DH_KC 8                                   // vocabulary entries (k) per staged chunk
+#define DH_NBUF 4                                 // LDS ring depth
+#define DH_BF (DH_KC * 512)                       // floats of the W slice of a chunk (16 KiB)
+#define DH_SLOTF (DH_BF + 4 * 256)                // + 4 M-tiles of G fragments (4 KiB)
+#define DH_REDF (4 * 64 * 33)                     // cross-wave dPred reduction scratch
 
-// One 8-wide k chunk (k = vocabulary index): 32 MFMAs.  Same single-buffer rolling refill
-// as the forward kernel: the logits slices of chunk c+1 are requested once G has been
-// generated from chunk c's, and W row s of chunk c+1 right after the 8 MFMAs that read row
-// s of chunk c.  Steady-state loads are unconditional (exact vmcnt counting); the last chunk
-// is peeled.  `kill` zeroes G for lanes whose k range lies beyond V (V % 8 == 4 tail).
-template <bool LAST>
-__device__ __forceinline__ void dh_chunk(DhFrag &f, const CellCoef (&cf)[2], int vb, int blank,
-                                         bool kill, const float *x0n, const float *x1n,
-                                         const float *wn, int H, f32x16 (&acc)[2][4])
-{
-    float g[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int dy = cf[mt].y - vb;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float e = __builtin_amdgcn_exp2f(fmaf(f.x[mt][s], RNNT_LOG2E, cf[mt].c1));
-            if (dy == s) e -= cf[mt].se;
-            if (vb + s == blank) e -= cf[mt].sb;
-            g[mt][s] = (LAST && kill) ? 0.f : e;
-        }
-    }
-    if (!LAST) {
-        f.x[0] = *(const f32x4 *)x0n;
-        f.x[1] = *(const f32x4 *)x1n;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                acc[mt][q] =
-                    __builtin_amdgcn_mfma_f32_32x32x2f32(g[mt][s], f.w[s][q], acc[mt][q], 0, 0, 0);
-        if (!LAST) f.w[s] = *(const f32x4 *)(wn + (long)s * H);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// grid (n_ublk, n_ttile, B * n_hblk); 8 waves = 2(M) x 4(N); wave tile 64 cells x 128 cols.
+// dHidden GEMM: dHidden[c,:] = G[c,:] @ W   (M = 128 cells = 8 t x 16 u of one utterance,
+// K = V, N = 512 columns of H per workgroup).  8 waves = 2 (M) x 4 (N), wave tile 64 x 128
+// (8 accumulator tiles).  Same machinery as the forward kernel: both operands go HBM/L2 -> LDS
+// by LDS-DMA into a DH_NBUF-deep ring two chunks ahead (W: 8 rows x 2 KiB; G: one 1 KiB
+// fragment-ordered piece per 32-cell M-tile, gathered with per-lane source addresses),
+// fragments are 16-byte LDS reads issued right after the MFMAs that consumed the previous
+// ones, counted vmcnt + one s_barrier per chunk.  No VALU work in the loop: G was produced by
+// k_make_g (cells outside the lattice are zero rows; tile rows outside [T,U1] read the zero
+// padding row).
+// grid (n_ublk, n_ttile, B * n_hblk).
 __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
 {
-    __shared__ float s_red[4][64][33];
+    __shared__ __attribute__((aligned(16))) float smem[DH_NBUF * DH_SLOTF + DH_REDF];
+    float(*s_red)[64][33] = (float(*)[64][33])(smem + DH_NBUF * DH_SLOTF);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -90,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
     const int col = ncol0 + 4 * i;
     const bool colok = col < H;
     const bool wave_on = ncol0 < H;
+    const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0, hidden == 0
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -99,49 +73,88 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
 
-    if (wave_on) {
-        CellCoef cf[2];
-        const float *lptr[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = wm * 64 + mt * 32 + i;
+    {
+        const int VK = (V + DH_KC - 1) / DH_KC;
+        // ---- DMA sources.  G piece of M-tile `wave` (waves 0-3): lane (i,half) fetches the
+        // 16 bytes G[cell(row wave*32+i)][k0 + 4*half ..]; that is already the MFMA A-fragment
+        // order, so the LDS image is lane-linear.
+        const float *gsrc = nullptr;
+        if (wave < 4) {
+            const int row = wave * 32 + i;
             const int t = t0 + (row >> 4), u = u0 + (row & 15);
-            const bool ok = t < Tb && u < U1;
-            const long cell = ((long)b * T + (ok ? t : t0)) * U1 + (ok ? u : u0);
-            cf[mt] = a.coef[cell];
-            if (!ok) { cf[mt].c1 = RNNT_NEG_INF; cf[mt].sb = 0.f; cf[mt].se = 0.f; cf[mt].y = -1; }
-            lptr[mt] = a.logits + cell * V + 4 * half;
+            const long cell = (t < T && u < U1) ? ((long)b * T + t) * U1 + u : zero_row;
+            gsrc = a.logits + cell * V + 4 * half;
         }
-        // columns beyond H (last column block only) read column 0 instead: their products
-        // land in accumulator columns that are never stored
-        const float *wptr = a.W + (long)(4 * half) * H + (colok ? col : 0);
-        const int VK = (V + 7) / 8;
-        // V % 8 == 4: in the last chunk lanes 32-63 would read k >= V; step them back 4
-        const bool kill = ((V & 7) != 0) && half == 1;
-        const int back = kill ? 4 : 0;
-        DhFrag f;
-        {
-            const int b0 = (VK == 1) ? back : 0;
-            f.x[0] = *(const f32x4 *)(lptr[0] - b0);
-            f.x[1] = *(const f32x4 *)(lptr[1] - b0);
+        // W slice: 16 pieces of 1 KiB per chunk, piece x = wave*2 + j: row x>>1, half-row x&1
+        const float *zsrc = a.hidden + zero_row * H;          // >= 16 B of zeros for k >= V
+        const int n_own = wave < 4 ? 3 : 2;                   // VMEM ops this wave issues per chunk
+        auto dma = [&](int c8, int slot) {
+            float *dst = smem + slot * DH_SLOTF;
+            const int k0 = c8 * DH_KC;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) f.w[s] = *(const f32x4 *)(wptr + (long)(s - b0) * H);
+            for (int j = 0; j < 2; ++j) {
+                const int x = wave * 2 + j, row = x >> 1, hx = x & 1;
+                const int cx = min(hb * 512 + hx * 256 + 4 * lane, H - 4);
+                const float *src = (k0 + row < V) ? a.W + (long)(k0 + row) * H + cx : zsrc;
+                __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)(dst + row * 512 + hx * 256), 16,
+                                                 0, 0);
+            }
+            if (wave < 4) {
+                // V % 8 == 4 tail: lanes 32-63 would start at k >= V; they re-read k0 (finite)
+                // and meet zero W rows, contributing 0
+                const int kk = (k0 + 4 * half < V) ? k0 : k0 - 4;
+                __builtin_amdgcn_global_load_lds(gsrc + kk, (lds_void_ptr)(dst + DH_BF + wave * 256),
+                                                 16, 0, 0);
+            }
+        };
+        const int a_off = DH_BF + (wm * 2) * 256 + 4 * lane;           // + mt*256
+        const int b_off = (4 * half) * 512 + wn * 128 + 4 * i;         // + s*512
+        f32x4 x4[2], w4[4];
+        dma(0, 0);
+        if (VK > 1) dma(1, 1);
+        if (VK > 2) dma(2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) x4[mt] = *(const f32x4 *)(smem + a_off + mt * 256);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) w4[s_] = *(const f32x4 *)(smem + b_off + s_ * 512);
+        for (int c8 = 0; c8 < VK; ++c8) {
+            // retire own DMA of chunk c8+1 (issued two iterations ago); the newest stays in flight
+            if (c8 + 2 >= VK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing newer
+            else if (n_own == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (c8 + 3 < VK) dma(c8 + 3, (c8 + 3) & (DH_NBUF - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments of chunk c8+1 (clamped at the end: re-reads the last chunk, unused)
+            const float *nx = smem + ((c8 + 1 < VK ? c8 + 1 : c8) & (DH_NBUF - 1)) * DH_SLOTF;
+            float g[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) g[mt][s_] = x4[mt][s_];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) x4[mt] = *(const f32x4 *)(nx + a_off + mt * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[mt][s_], w4[s_][q],
+                                                                          acc[mt][q], 0, 0, 0);
+                w4[s_] = *(const f32x4 *)(nx + b_off + s_ * 512);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        for (int c8 = 0; c8 + 2 < VK; ++c8) {
-            const int kn = 8 * (c8 + 1);
-            dh_chunk<false>(f, cf, 8 * c8 + 4 * half, a.blank, false, lptr[0] + kn, lptr[1] + kn,
-                            wptr + (long)kn * H, H, acc);
-        }
-        if (VK >= 2) {
-            const int c8 = VK - 2, kn = 8 * (c8 + 1) - back;
-            dh_chunk<false>(f, cf, 8 * c8 + 4 * half, a.blank, false, lptr[0] + kn, lptr[1] + kn,
-                            wptr + (long)kn * H, H, acc);
-        }
-        dh_chunk<true>(f, cf, 8 * (VK - 1) + 4 * half, a.blank, kill, nullptr, nullptr, nullptr, H,
-                       acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // ---- epilogue: dPre = dHidden * (1 - tanh^2); reduce over u (dEnc) and over t (dPred)
+    // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
     float psum[8][4];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -157,21 +170,17 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
                 const int tl = wm * 4 + mt * 2 + rh;
                 const int t = t0 + tl;
                 const bool tok = t < Tb;
-                f32x4 e4 = {0.f, 0.f, 0.f, 0.f};
-                if (tok && colok)
-                    e4 = *(const f32x4 *)(a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + col);
                 float esum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r7 = 0; r7 < 8; ++r7) {
                     const int ul = 8 * (r7 >> 2) + 4 * half + (r7 & 3);
                     const int u = u0 + ul;
                     const bool ok = tok && u < U1 && colok;
-                    f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) p4 = *(const f32x4 *)(a.pred + ((long)b * U1 + u) * H + col);
+                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) h4 = *(const f32x4 *)(a.hidden + (((long)b * T + t) * U1 + u) * H + col);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float h = fast_tanh(e4[q] + p4[q]);
-                        const float d = ok ? acc[mt][q][rh * 8 + r7] * (1.f - h * h) : 0.f;
+                        const float d = ok ? acc[mt][q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
                         esum[q] += d;
                         psum[r7][q] += d;
                     }
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
                 }
             }
     }
+    __syncthreads();  // every wave is past its last ring read before s_red (same array) is used
     if (wm == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -253,121 +263,120 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------
-// dW split-K GEMM.  grid (n_vblk, n_hblk, n_split); 4 waves = 2(M) x 2(N); wave tile
-// 128 (v) x 128 (h) = 16 accumulator tiles (256 VGPRs, one wave per SIMD).
-struct DwRaw {
-    f32x4 x;  // logits[cell][v0+4i .. +3]
-    f32x4 p;  // pred[b,u][h0+4j .. +3]
-    f32x4 e;  // enc[b,t][h0+4j .. +3]
+// Elementwise producers for the backward GEMMs (HBM-bound, a few ms at the BASELINE sizes):
+//   k_make_hidden  hidden[c,:] = tanh(enc[b,t,:] + pred[b,u,:])          (rnnt/joint.py:32-37)
+//   k_make_g       logits[c,:] -> G[c,:] IN PLACE (formula at the top of this file); cells
+//                  outside the lattice and the zero-padding rows become exact zeros
+// so that both backward GEMMs are pure matrix products whose operands stream HBM -> LDS by
+// LDS-DMA with no VALU work in the main loops (operand generation inside the dW loop cost
+// ~10 VALU per MFMA and held it at 46 % of the matrix pipe).
+__global__ __launch_bounds__(256) void k_make_hidden(const float *__restrict__ enc, long sb,
+                                                     long st_, const float *__restrict__ pred,
+                                                     float *__restrict__ hid, int B, int T, int U1,
+                                                     int H, long rows_pad)
+{
+    const int H4 = H / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows_pad * H4) return;
+    const long c = idx / H4;
+    const int h = (int)(idx - c * H4) * 4;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (c < (long)B * T * U1) {
+        const int u = (int)(c % U1);
+        const long bt = c / U1;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const f32x4 e = *(const f32x4 *)(enc + (long)b * sb + (long)t * st_ + h);
+        const f32x4 p = *(const f32x4 *)(pred + ((long)b * U1 + u) * H + h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[q] + p[q]);
+    }
+    *(f32x4 *)(hid + c * H + h) = o;
+}
+
+__global__ __launch_bounds__(256) void k_make_g(float *__restrict__ logits,
+                                                const CellCoef *__restrict__ coef, long rows,
+                                                long rows_pad, int V, int blank)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_pad) return;
+    float *x = logits + row * V;
     CellCoef c;
-    bool live;  // false for padding k-steps and for the u == U1 half of an odd row
-};
-
-// Walks the (b,t) rows of this split, two lattice cells (u, u+1) per k-step, purely with
-// wave-uniform integer selects so that the software-pipelined loop body stays ONE basic
-// block with unconditional loads (exact vmcnt counting).
-struct DwCursor {
-    long bt, step;
-    int b, t, us;
-};
-
-struct DwLane {   // per-lane constants of the issue path
-    int vsafe, hsafe;  // first column of this lane's logits / hidden slice (clamped to 0)
-    int hV, hH, h1;    // half ? V : 0, half ? H : 0, half
-};
-
-__device__ __forceinline__ void dw_issue(DwRaw &r, DwCursor &c, const JointBwdArgs &a,
-                                         const DwLane &ln, long nstep, long bt_last, int SPB)
-{
-    const int U1 = a.U1;
-    // lanes 0-31 take cell u = 2*us, lanes 32-63 cell u+1; on the odd tail of a row the upper
-    // half re-reads cell u (valid memory) and is masked through `live`.  All row/step
-    // arithmetic is wave-uniform (SALU); the per-lane part is one select + adds.
-    const bool tail = (2 * c.us + 1) >= U1;
-    const long cell0 = c.bt * U1 + 2 * c.us;
-    const long prow0 = (long)c.b * U1 + 2 * c.us;
-    r.live = (c.step < nstep) && !(tail && ln.h1);
-    r.x = *(const f32x4 *)(a.logits + cell0 * a.V + ((tail ? 0 : ln.hV) + ln.vsafe));
-    r.p = *(const f32x4 *)(a.pred + prow0 * a.H + ((tail ? 0 : ln.hH) + ln.hsafe));
-    r.e = *(const f32x4 *)(a.enc + (long)c.b * a.enc_sb + (long)c.t * a.enc_st + ln.hsafe);
-    r.c = a.coef[cell0 + (tail ? 0 : ln.h1)];
-    // advance (stays on the last row once the split is exhausted: addresses remain valid)
-    c.step += 1;
-    const bool wrap = (c.us + 1) == SPB;
-    const bool adv = wrap && (c.bt < bt_last);
-    c.us = wrap ? 0 : c.us + 1;
-    const bool nb = adv && (c.t + 1 == a.T);
-    c.bt += adv ? 1 : 0;
-    c.t = adv ? (nb ? 0 : c.t + 1) : c.t;
-    c.b += nb ? 1 : 0;
-}
-
-// One k-step of the software pipeline, written as four sub-blocks so that the VALU work
-// that generates the NEXT step's operands (G = A operand, 4 interleaved v tiles; hidden =
-// B operand, 4 interleaved h tiles) issues in the shadow of the CURRENT step's 16 MFMAs:
-// sub-block q = {generate operand q of step s+1, 4 MFMAs of row q of step s}.  Cells
-// outside the lattice (k_coef marks them with c1 = -inf) contribute exactly 0.
-__device__ __forceinline__ void dw_step(const DwRaw &rn, float (&gN)[4], float (&hN)[4],
-                                        const float (&gC)[4], const float (&hC)[4], int vbase,
-                                        int blank, f32x16 (&acc)[4][4], float (&dbacc)[4])
-{
-    const bool ok = rn.live && (rn.c.c1 != RNNT_NEG_INF);
-    const float c1 = ok ? rn.c.c1 : RNNT_NEG_INF;
-    const float sb = ok ? rn.c.sb : 0.f, se = ok ? rn.c.se : 0.f;
-    const int dy = rn.c.y - vbase, db = blank - vbase;
+    c.c1 = RNNT_NEG_INF; c.sb = 0.f; c.se = 0.f; c.y = -1;
+    if (row < rows) c = coef[row];
+    const bool live = c.c1 != RNNT_NEG_INF;
+    for (int v = lane * 4; v < V; v += 256) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const f32x4 q = *(const f32x4 *)(x + v);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float x = ok ? rn.x[q] : 0.f;  // rows t >= T_b were never written by the forward
-        float e = __builtin_amdgcn_exp2f(fmaf(x, RNNT_LOG2E, c1));
-        if (dy == q) e -= se;
-        if (db == q) e -= sb;
-        gN[q] = e;
-        dbacc[q] += e;
-        hN[q] = fast_tanh(rn.e[q] + rn.p[q]);
-#pragma unroll
-        for (int qn = 0; qn < 4; ++qn)
-            acc[q][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(gC[q], hC[qn], acc[q][qn], 0, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // 5 VALU in its shadow
+            for (int s = 0; s < 4; ++s) {
+                float e = __builtin_amdgcn_exp2f(fmaf(q[s], RNNT_LOG2E, c.c1));
+                if (v + s == blank) e -= c.sb;
+                if (v + s == c.y) e -= c.se;
+                o[s] = e;
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        *(f32x4 *)(x + v) = o;
     }
 }
 
-__device__ __forceinline__ void dw_gen_first(const DwRaw &r, int vbase, int blank, float (&g)[4],
-                                             float (&hd)[4], float (&dbacc)[4])
+void launch_make_hidden(const JointBwdArgs &a, hipStream_t st)
 {
-    const bool ok = r.live && (r.c.c1 != RNNT_NEG_INF);
-    const float c1 = ok ? r.c.c1 : RNNT_NEG_INF;
-    const float sb = ok ? r.c.sb : 0.f, se = ok ? r.c.se : 0.f;
-    const int dy = r.c.y - vbase, db = blank - vbase;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float x = ok ? r.x[q] : 0.f;
-        float e = __builtin_amdgcn_exp2f(fmaf(x, RNNT_LOG2E, c1));
-        if (dy == q) e -= se;
-        if (db == q) e -= sb;
-        g[q] = e;
-        dbacc[q] += e;
-        hd[q] = fast_tanh(r.e[q] + r.p[q]);
-    }
+    const long n = a.rows_pad * (a.H / 4);
+    hipLaunchKernelGGL(k_make_hidden, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.enc,
+                       a.enc_sb, a.enc_st, a.pred, a.hidden, a.B, a.T, a.U1, a.H, a.rows_pad);
 }
+
+void launch_make_g(const JointBwdArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_make_g, dim3((unsigned)((a.rows_pad + 3) / 4)), dim3(256), 0, st,
+                       (float *)a.logits, a.coef, (long)a.B * a.T * a.U1, a.rows_pad, a.V, a.blank);
+}
+
+// ---------------------------------------------------------------------------------------
+// dW split-K GEMM:  dW[v,h] = sum_c G[c,v] * hidden[c,h]   (M = V, N = H, K = lattice cells).
+//
+// Workgroup = 4 waves (one per SIMD) = 2 (M) x 2 (N); workgroup tile 256 (v) x 256 (h); each
+// wave owns 128 x 128 = 16 accumulator tiles (256 AGPRs).  Both operands are row-major with the
+// K index (cell) as the row, so a chunk of DW_KC cells is DW_KC contiguous 1 KiB row slices per
+// operand: they go HBM -> LDS by LDS-DMA (one wave instruction per row slice, no VGPRs) into a
+// DW_NBUF-deep ring, two chunks ahead, behind counted vmcnt waits and one s_barrier per
+// chunk.  Fragments are 16-byte LDS reads: a lane's 4 consecutive v (or h) are 4 interleaved
+// MFMA tiles (tile q holds rows 4i+q), so one read feeds 4 tiles and the epilogue stores are
+// 16-byte coalesced.  k-step ks multiplies cells 2ks (lanes 0-31) and 2ks+1 (lanes 32-63).
+// The grid is 1-D and XCD-aware: the tiles of one split (same cells, different v/h blocks)
+// get consecutive remapped ids and therefore share an XCD's L2.
+#define DW_KC 16
+#define DW_NBUF 3
+#define DW_ROWF 256                      // floats per staged row slice (1 KiB)
+#define DW_CHUNKF (2 * DW_KC * DW_ROWF)  // floats per ring slot: A rows then B rows
 
 __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
 {
+    __shared__ __attribute__((aligned(16))) float smem[DW_NBUF * DW_CHUNKF];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
-    const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
-    const int v0 = blockIdx.x * 256 + wm * 128;
-    const int h0 = blockIdx.y * 256 + wn * 128;
-    const int split = blockIdx.z;
+    const int H = a.H, V = a.V;
+    const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
+    const int tiles = n_vblk * n_hblk;
+    const int total = tiles * a.n_split;
+    // XCD-aware remap (bijective for any total): ids that are congruent mod 8 share an XCD
+    int id = blockIdx.x;
+    {
+        const int q8 = total / 8, r8 = total % 8, x = id % 8;
+        id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + id / 8;
+    }
+    const int tile = id % tiles, split = id / tiles;
+    const int vb = tile / n_hblk, hb = tile % n_hblk;
+    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
     const int vbase = v0 + 4 * i, hbase = h0 + 4 * i;
     const bool vok = vbase < V, hok = hbase < H;
-    const long nbt = (long)a.B * T;
-    const long bt_lo = nbt * split / a.n_split, bt_hi = nbt * (split + 1) / a.n_split;
+    const long nchunk = a.rows_pad / DW_KC;
+    const long k_lo = nchunk * split / a.n_split, k_hi = nchunk * (split + 1) / a.n_split;
+    const int nk = (int)(k_hi - k_lo);
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -378,43 +387,55 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (v0 < V && h0 < H && bt_hi > bt_lo) {  // wave-uniform
-        const int SPB = (U1 + 1) / 2;
-        const long nstep = (bt_hi - bt_lo) * SPB;
-        // rows / columns beyond V / H (edge tiles) read row/column 0: their results sit in
-        // accumulator rows / columns that are never stored
-        DwLane ln;
-        ln.vsafe = vok ? vbase : 0; ln.hsafe = hok ? hbase : 0;
-        ln.hV = half ? V : 0; ln.hH = half ? H : 0; ln.h1 = half;
-        DwCursor cur;
-        cur.bt = bt_lo; cur.step = 0; cur.us = 0;
-        cur.b = (int)(bt_lo / T); cur.t = (int)(bt_lo - (long)cur.b * T);
-        const long bt_last = bt_hi - 1;
-        DwRaw r0, r1, r2, r3;
-        float gA[4], hA[4], gB[4], hB[4];
-        // 4 raw k-steps in flight (~4 x 1024 matrix-pipe cycles of lead for the HBM-streamed
-        // logits); operands of step s+1 are generated while the 16 MFMAs of step s issue.
-        dw_issue(r0, cur, a, ln, nstep, bt_last, SPB);
-        dw_issue(r1, cur, a, ln, nstep, bt_last, SPB);
-        dw_issue(r2, cur, a, ln, nstep, bt_last, SPB);
-        dw_issue(r3, cur, a, ln, nstep, bt_last, SPB);
-        dw_gen_first(r0, vbase, a.blank, gA, hA, dbacc);
-        dw_issue(r0, cur, a, ln, nstep, bt_last, SPB);
-        __builtin_amdgcn_sched_barrier(0);
-        for (long s = 0; s < nstep; s += 4) {
-            // at the top: (gA,hA) = operands of step s; r1..r3,r0 hold raw steps s+1..s+4
-            dw_step(r1, gB, hB, gA, hA, vbase, a.blank, acc, dbacc);
-            dw_issue(r1, cur, a, ln, nstep, bt_last, SPB);
+    if (nk > 0) {  // workgroup-uniform
+        // DMA sources: lane l of a row slice reads floats [4l, 4l+4); columns beyond V / H (edge
+        // tiles) re-read the last valid 16 bytes: they only feed accumulators never stored
+        const int vcol = min(vb * 256 + 4 * lane, V - 4), hcol = min(hb * 256 + 4 * lane, H - 4);
+        const float *gsrc = a.logits + (k_lo * DW_KC) * (long)V + vcol;
+        const float *hsrc = a.hidden + (k_lo * DW_KC) * (long)H + hcol;
+        auto dma = [&](int k, int slot) {  // rows wave, wave+4, wave+8, wave+12 of both operands
+            float *dst = smem + slot * DW_CHUNKF;
+#pragma unroll
+            for (int j = 0; j < DW_KC / 4; ++j) {
+                const int r = wave + 4 * j;
+                __builtin_amdgcn_global_load_lds(gsrc + ((long)k * DW_KC + r) * V,
+                                                 (lds_void_ptr)(dst + r * DW_ROWF), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(hsrc + ((long)k * DW_KC + r) * H,
+                                                 (lds_void_ptr)(dst + (DW_KC + r) * DW_ROWF), 16, 0,
+                                                 0);
+            }
+        };
+        const int aoff = half * DW_ROWF + wm * 128 + 4 * i;                   // A fragment, ks = 0
+        const int boff = (DW_KC + half) * DW_ROWF + wn * 128 + 4 * i;         // B fragment, ks = 0
+        dma(0, 0);
+        if (nk > 1) dma(1, 1);
+        for (int k = 0; k < nk; ++k) {
+            // own DMA of chunk k done (chunk k+1's 8 ops may stay in flight), then publish
+            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            dw_step(r2, gA, hA, gB, hB, vbase, a.blank, acc, dbacc);
-            dw_issue(r2, cur, a, ln, nstep, bt_last, SPB);
+            if (k + 2 < nk) dma(k + 2, (k + 2) % DW_NBUF);
             __builtin_amdgcn_sched_barrier(0);
-            dw_step(r3, gB, hB, gA, hA, vbase, a.blank, acc, dbacc);
-            dw_issue(r3, cur, a, ln, nstep, bt_last, SPB);
-            __builtin_amdgcn_sched_barrier(0);
-            dw_step(r0, gA, hA, gB, hB, vbase, a.blank, acc, dbacc);
-            dw_issue(r0, cur, a, ln, nstep, bt_last, SPB);
-            __builtin_amdgcn_sched_barrier(0);
+            const float *sl = smem + (k % DW_NBUF) * DW_CHUNKF;
+            f32x4 a4 = *(const f32x4 *)(sl + aoff), b4 = *(const f32x4 *)(sl + boff);
+#pragma unroll
+            for (int ks = 0; ks < DW_KC / 2; ++ks) {
+                f32x4 an = a4, bn = b4;
+                if (ks + 1 < DW_KC / 2) {
+                    an = *(const f32x4 *)(sl + aoff + (ks + 1) * 2 * DW_ROWF);
+                    bn = *(const f32x4 *)(sl + boff + (ks + 1) * 2 * DW_ROWF);
+                }
+#pragma unroll
+                for (int qm = 0; qm < 4; ++qm) {
+                    dbacc[qm] += a4[qm];
+#pragma unroll
+                    for (int qn = 0; qn < 4; ++qn)
+                        acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qm], b4[qn],
+                                                                           acc[qm][qn], 0, 0, 0);
+                }
+                a4 = an; b4 = bn;
+            }
         }
     }
 
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
                 }
             }
     }
-    if (blockIdx.y == 0 && wn == 0) {
+    if (hb == 0 && wn == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dbacc[q] += __shfl_xor(dbacc[q], 32, 64);
         if (half == 0 && vok) {
@@ -456,8 +477,8 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ 
 
 void launch_dw(const JointBwdArgs &a, hipStream_t st)
 {
-    dim3 grid((a.V + 255) / 256, (a.H + 255) / 256, a.n_split);
-    hipLaunchKernelGGL(k_dw, grid, dim3(256), 0, st, a);
+    const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
+    hipLaunchKernelGGL(k_dw, dim3(tiles * a.n_split), dim3(256), 0, st, a);
     const long n4w = (long)a.V * a.H / 4;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4w + 255) / 256)), dim3(256), 0, st,
                        a.slab_w, a.grad_W, n4w, a.n_split);

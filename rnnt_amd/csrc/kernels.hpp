@@ -43,7 +43,9 @@ struct JointBwdArgs {
     const float *enc; long enc_sb, enc_st;
     const float *pred;
     const float *W;       // [V,H] natural layout
-    const float *logits;  // [B,T,U1,V]
+    const float *logits;  // [rows_pad,V]: logits, overwritten by G (k_make_g)
+    float *hidden;        // [rows_pad,H] tanh(enc+pred) (k_make_hidden)
+    long rows_pad;        // B*T*U1 rounded up to a multiple of 16 (zero rows)
     const CellCoef *coef; // [B,T,U1]
     const int32_t *logit_lens;
     float *slab_enc;   // [n_ublk][B,T,H]
@@ -56,3 +58,5 @@ struct JointBwdArgs {
 };
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);
+void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
+void launch_make_g(const JointBwdArgs &a, hipStream_t st);
