@@ -57,15 +57,15 @@ void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
     const size_t D = (size_t)T + U1 - 1;
     const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
     // G / hidden rows are padded with >= 1 zero row up to a multiple of 16 (dW chunk size)
-    const size_t rows_pad = (cells + 1 + 15) / 16 * 16;
+    const size_t rows_pad = (cells + 1 + 15) / 16 * 16;  // buffers get 16 more rows (dW ring overrun)
     L->rows_pad = rows_pad;
     L->D = (int)D;
     L->n_ublk = (U1 + 15) / 16;
     L->n_ttile = (T + 7) / 8;
     L->n_split = dw_splits(B, T, H, V);
     size_t o = 0;
-    L->logits = o;   o += align_up(rows_pad * V * 4);
-    L->hidden = o;   o += align_up(rows_pad * H * 4);
+    L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
+    L->hidden = o;   o += align_up((rows_pad + 16) * H * 4);
     L->denom_s = o;  o += align_up(skew * 4);
     L->lpb_s = o;    o += align_up(skew * 4);
     L->lpe_s = o;    o += align_up(skew * 4);

@@ -339,24 +339,27 @@ void launch_make_g(const JointBwdArgs &a, hipStream_t st)
 //
 // Workgroup = 4 waves (one per SIMD) = 2 (M) x 2 (N); workgroup tile 256 (v) x 256 (h); each
 // wave owns 128 x 128 = 16 accumulator tiles (256 AGPRs).  Both operands are row-major with the
-// K index (cell) as the row, so a chunk of DW_KC cells is DW_KC contiguous 1 KiB row slices per
-// operand: they go HBM -> LDS by LDS-DMA (one wave instruction per row slice, no VGPRs) into a
-// DW_NBUF-deep ring, two chunks ahead, behind counted vmcnt waits and one s_barrier per
-// chunk.  Fragments are 16-byte LDS reads: a lane's 4 consecutive v (or h) are 4 interleaved
-// MFMA tiles (tile q holds rows 4i+q), so one read feeds 4 tiles and the epilogue stores are
-// 16-byte coalesced.  k-step ks multiplies cells 2ks (lanes 0-31) and 2ks+1 (lanes 32-63).
+// K index (cell) as the row: k-step ks multiplies cells 2ks (lanes 0-31) and 2ks+1 (lanes
+// 32-63), and a lane's 16-byte load of 4 consecutive v (or h) feeds 4 interleaved MFMA tiles
+// (tile q holds rows 4i+q), so the epilogue stores are 16-byte coalesced too.
+//
+// Operand path (measured, tools/mfma_mix*.hip): register-destination global loads cost the
+// matrix pipe nothing to issue, whereas every LDS-DMA piece costs ~60 cycles of issue and an
+// LDS ring adds barriers — so the fragments go straight HBM/L2 -> VGPR through a DW_RING-deep
+// register ring (8 k-steps = 8192 matrix-pipe cycles of lead, enough for an HBM miss), all
+// loads unconditional and compiler-visible (inline-asm ring loads were tried: hipcc's allocator
+// copies the still-pending destinations across the loop back-edge); no LDS, no barrier, no
+// VALU in the loop except the 4 adds of the bias gradient.  The two waves that share an operand slice
+// (same wm or same wn) run in step and meet in L1/L2.
 // The grid is 1-D and XCD-aware: the tiles of one split (same cells, different v/h blocks)
 // get consecutive remapped ids and therefore share an XCD's L2.
-#define DW_KC 16
-#define DW_NBUF 3
-#define DW_ROWF 256                      // floats per staged row slice (1 KiB)
-#define DW_CHUNKF (2 * DW_KC * DW_ROWF)  // floats per ring slot: A rows then B rows
+#define DW_KC 16   // cells per split-range granule (row padding unit)
+#define DW_RING 8  // k-steps of operands in flight per wave
 
 __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float smem[DW_NBUF * DW_CHUNKF];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
     const int H = a.H, V = a.V;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
     const bool vok = vbase < V, hok = hbase < H;
     const long nchunk = a.rows_pad / DW_KC;
     const long k_lo = nchunk * split / a.n_split, k_hi = nchunk * (split + 1) / a.n_split;
-    const int nk = (int)(k_hi - k_lo);
+    const long nstep = (k_hi - k_lo) * (DW_KC / 2);  // k-steps (cell pairs); multiple of DW_RING
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -387,45 +390,28 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) {  // workgroup-uniform
-        // DMA sources: lane l of a row slice reads floats [4l, 4l+4); columns beyond V / H (edge
-        // tiles) re-read the last valid 16 bytes: they only feed accumulators never stored
-        const int vcol = min(vb * 256 + 4 * lane, V - 4), hcol = min(hb * 256 + 4 * lane, H - 4);
-        const float *gsrc = a.logits + (k_lo * DW_KC) * (long)V + vcol;
-        const float *hsrc = a.hidden + (k_lo * DW_KC) * (long)H + hcol;
-        auto dma = [&](int k, int slot) {  // rows wave, wave+4, wave+8, wave+12 of both operands
-            float *dst = smem + slot * DW_CHUNKF;
+    if (nstep > 0) {  // workgroup-uniform
+        // columns beyond V / H (edge tiles) re-read the last valid 16 bytes: they only feed
+        // accumulators that are never stored.  The buffers carry DW_KC extra zero rows, so the
+        // ring may run DW_RING k-steps past the end of the last split.
+        const float *gp = a.logits + (k_lo * DW_KC + half) * (long)V + (vok ? vbase : V - 4);
+        const float *hp = a.hidden + (k_lo * DW_KC + half) * (long)H + (hok ? hbase : H - 4);
+        const long gstep = 2L * V, hstep = 2L * H;
+        f32x4 ra[DW_RING], rb[DW_RING];
 #pragma unroll
-            for (int j = 0; j < DW_KC / 4; ++j) {
-                const int r = wave + 4 * j;
-                __builtin_amdgcn_global_load_lds(gsrc + ((long)k * DW_KC + r) * V,
-                                                 (lds_void_ptr)(dst + r * DW_ROWF), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(hsrc + ((long)k * DW_KC + r) * H,
-                                                 (lds_void_ptr)(dst + (DW_KC + r) * DW_ROWF), 16, 0,
-                                                 0);
-            }
-        };
-        const int aoff = half * DW_ROWF + wm * 128 + 4 * i;                   // A fragment, ks = 0
-        const int boff = (DW_KC + half) * DW_ROWF + wn * 128 + 4 * i;         // B fragment, ks = 0
-        dma(0, 0);
-        if (nk > 1) dma(1, 1);
-        for (int k = 0; k < nk; ++k) {
-            // own DMA of chunk k done (chunk k+1's 8 ops may stay in flight), then publish
-            if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 2 < nk) dma(k + 2, (k + 2) % DW_NBUF);
-            __builtin_amdgcn_sched_barrier(0);
-            const float *sl = smem + (k % DW_NBUF) * DW_CHUNKF;
-            f32x4 a4 = *(const f32x4 *)(sl + aoff), b4 = *(const f32x4 *)(sl + boff);
+        for (int s_ = 0; s_ < DW_RING; ++s_) {
+            ra[s_] = *(const f32x4 *)(gp + s_ * gstep);
+            rb[s_] = *(const f32x4 *)(hp + s_ * hstep);
+        }
+        gp += DW_RING * gstep;
+        hp += DW_RING * hstep;
+        for (long st = 0; st < nstep; st += DW_RING) {
 #pragma unroll
-            for (int ks = 0; ks < DW_KC / 2; ++ks) {
-                f32x4 an = a4, bn = b4;
-                if (ks + 1 < DW_KC / 2) {
-                    an = *(const f32x4 *)(sl + aoff + (ks + 1) * 2 * DW_ROWF);
-                    bn = *(const f32x4 *)(sl + boff + (ks + 1) * 2 * DW_ROWF);
-                }
+            for (int s_ = 0; s_ < DW_RING; ++s_) {
+                const f32x4 a4 = ra[s_], b4 = rb[s_];
+                ra[s_] = *(const f32x4 *)(gp + s_ * gstep);  // k-step st + s_ + DW_RING
+                rb[s_] = *(const f32x4 *)(hp + s_ * hstep);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int qm = 0; qm < 4; ++qm) {
                     dbacc[qm] += a4[qm];
@@ -434,8 +420,10 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
                         acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qm], b4[qn],
                                                                            acc[qm][qn], 0, 0, 0);
                 }
-                a4 = an; b4 = bn;
+                __builtin_amdgcn_sched_barrier(0);
             }
+            gp += DW_RING * gstep;
+            hp += DW_RING * hstep;
         }
     }
 
