@@ -137,9 +137,9 @@ def main():
         dist.broadcast(W, 0); dist.broadcast(bias, 0)
     scale = 1.0 / B
     # flat [dW | db | loss] buffer: grad_W / grad_bias are views, so the all-reduce needs no copy
-    flat = torch.zeros(V * H + V + 4, dtype=torch.float32, device=device)
-    gW = flat[:V * H].view(V, H)
-    gb = flat[V * H:V * H + V]
+    from rnnt_amd.parallel import FlatGrad
+    fg = FlatGrad(V, H, device)
+    flat, gW, gb = fg.flat, fg.grad_W, fg.grad_bias
     costs = torch.empty(Bl, dtype=torch.float32, device=device)
     ge = torch.empty(Bl, T, H, dtype=torch.float32, device=device)
     gp = torch.empty(Bl, U + 1, H, dtype=torch.float32, device=device)
@@ -147,9 +147,8 @@ def main():
 
     def step():
         engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs)
-        flat[V * H + V] = costs.sum() * scale
-        if world > 1:
-            dist.all_reduce(flat)  # one RCCL all-reduce over xGMI: dW, db and the loss
+        fg.set_loss(costs, scale)
+        fg.all_reduce()  # N>1: one RCCL all-reduce over xGMI of dW, db and the loss
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,77 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every symbol include/*.h
+declares, and its host-side argument handling works without a GPU (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rnnt_amd import engine
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build()
+    return engine.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rnnt_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rnnt_engine_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rnnt_engine.h but not exported"
+
+
+def test_python_binding_lists_every_entry_point():
+    from rnnt_amd import engine
+    declared = set(_declared_symbols())
+    assert set(engine.EXPORTS) <= declared
+
+
+def test_version_and_workspace_queries(lib):
+    assert lib.rnnt_engine_version() >= 1
+    n = ctypes.c_size_t(0)
+    assert lib.rnnt_engine_workspace_bytes(32, 1000, 201, 512, 1024, 0, ctypes.byref(n)) == 0
+    logits = 32 * 1000 * 201 * 1024 * 4
+    assert logits < n.value < 2 * logits  # logits + hidden + slabs, never a second logits copy
+    m = ctypes.c_size_t(0)
+    assert lib.rnnt_engine_loss_workspace_bytes(2, 5, 3, 8, 0, ctypes.byref(m)) == 0 and m.value > 0
+    assert lib.rnnt_engine_joint_fwd_workspace_bytes(2, 5, 3, 16, 8, 0, ctypes.byref(m)) == 0
+
+
+def test_error_codes_and_messages(lib):
+    lib.rnnt_engine_last_error.restype = ctypes.c_char_p
+    n = ctypes.c_size_t(0)
+    assert lib.rnnt_engine_workspace_bytes(0, 5, 3, 16, 8, 0, ctypes.byref(n)) == -1
+    assert b"non-positive" in lib.rnnt_engine_last_error()
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 16, 6, 0, ctypes.byref(n)) == -2      # V % 4
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 18, 8, 0, ctypes.byref(n)) == -2      # H % 4
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 2000, 16, 8, 0, ctypes.byref(n)) == -2   # U1
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 16, 8, 7, ctypes.byref(n)) == -2      # dtype
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 16, 8, 0, None) == -1
+    # null pointers are rejected before anything is launched
+    strides = (ctypes.c_int64 * 3)(80, 16, 1)
+    rc = lib.rnnt_engine_joint_loss_fwd_bwd(None, strides, None, None, None, None, None, None, 2, 5,
+                                            3, 16, 8, 7, ctypes.c_float(-1), ctypes.c_float(0.5), 0,
+                                            None, None, None, None, None, None, ctypes.c_size_t(0),
+                                            None)
+    assert rc == -1 and b"null" in lib.rnnt_engine_last_error()
+
+
+def test_layout_is_consistent(lib):
+    from rnnt_amd import engine
+    L = engine.layout(3, 17, 9, 64, 32)
+    offs = [L.logits, L.hidden, L.denom_s, L.lpb_s, L.lpe_s, L.alpha_s, L.beta_s, L.coef, L.wpack,
+            L.enc_copy, L.slab_enc, L.slab_pred, L.slab_w, L.slab_b, L.total]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert L.D == 17 + 9 - 1 and L.n_ublk == 1 and L.n_ttile == 3
+    assert L.rows_pad % 16 == 0 and L.rows_pad > 3 * 17 * 9
+    assert L.total == engine.workspace_bytes(3, 17, 9, 64, 32)

@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the batch, each computes its shard's
+joint+loss gradients (the CPU oracle stands in for the engine call — no GPU here), and ONE
+all-reduce of the flat [dW | db | loss] buffer must reproduce the full-batch result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu_oracle
+    from rnnt_amd.parallel import FlatGrad, shard_bounds
+    from tests.helpers import make_inputs
+    B, T, U, H, V = 5, 9, 4, 16, 8
+    d = make_inputs(B, T, U, H, V, seed=3)
+    lo, hi = shard_bounds(B, world, rank)
+    r = cpu_oracle.joint_loss_fwd_bwd(d["enc"][lo:hi], d["pred"][lo:hi], d["W"], d["bias"],
+                                      d["targets"][lo:hi], d["logit_lens"][lo:hi],
+                                      d["target_lens"][lo:hi], dtype=np.float64)
+    w = (hi - lo) / B  # the oracle returns shard-mean gradients; the engine gets grad_scale=1/B
+    fg = FlatGrad(V, H, "cpu")
+    fg.grad_W.copy_(torch.from_numpy(r["grad_W"] * w))
+    fg.grad_bias.copy_(torch.from_numpy(r["grad_bias"] * w))
+    fg.set_loss(torch.from_numpy(r["costs"]).float(), 1.0 / B)
+    fg.all_reduce()
+    if rank == 0:
+        np.savez(out, flat=fg.flat.numpy(), lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_matches_full_batch(tmp_path):
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    z = np.load(out)
+    from oracle import cpu_oracle
+    from tests.helpers import make_inputs
+    B, T, U, H, V = 5, 9, 4, 16, 8
+    d = make_inputs(B, T, U, H, V, seed=3)
+    full = cpu_oracle.joint_loss_fwd_bwd(d["enc"], d["pred"], d["W"], d["bias"], d["targets"],
+                                         d["logit_lens"], d["target_lens"], dtype=np.float64)
+    flat = z["flat"]
+    np.testing.assert_allclose(flat[:V * H].reshape(V, H), full["grad_W"], atol=1e-6)
+    np.testing.assert_allclose(flat[V * H:V * H + V], full["grad_bias"], atol=1e-6)
+    assert abs(flat[V * H + V] - full["loss"]) < 1e-4 * abs(full["loss"])
+    assert (int(z["lo"]), int(z["hi"])) == (0, 3)
+
+
+def test_shard_bounds_cover_batch():
+    from rnnt_amd.parallel import shard_bounds
+    for B in (1, 5, 32):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(B, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -1,0 +1,104 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no compute)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rnnt_amd
+
+
+def test_joint_network_mirrors_reference_interface(golden_dir):
+    """Constructor args, attribute names and state-dict keys of reference rnnt/joint.py:4-20."""
+    for name in ("joint_tiny", "joint_proj"):
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        Fa, Ft, H, V = (int(x) for x in z["ctor"])
+        m = rnnt_amd.JointNetwork(Fa, Ft, H, V)
+        ref_keys = sorted(k[4:].replace("__", ".") for k in z.files if k.startswith("sd__"))
+        assert sorted(m.state_dict().keys()) == ref_keys
+        assert m.blank_idx == V - 1
+        assert hasattr(m, "audio_ln") == (Fa > 0) and hasattr(m, "text_ln") == (Ft > 0)
+        m.load_state_dict({k: torch.from_numpy(z["sd__" + k.replace(".", "__")]) for k in ref_keys})
+        # single_forward (decode/export path, plain torch by design) reproduces the reference's
+        # logits frame by frame
+        a, t = torch.from_numpy(z["audio"]), torch.from_numpy(z["text"])
+        out = m.single_forward(a[:, 2, :], t[:, 1, :]).detach().numpy()
+        np.testing.assert_allclose(out, z["logits_f32"][:, 2, 1, :], rtol=0, atol=2e-5)
+
+
+def test_batch_forward_rejects_cpu_tensors():
+    """The hot path has no CPU fallback: CPU tensors fail loudly."""
+    m = rnnt_amd.JointNetwork(-1, -1, 16, 8)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.randn(2, 5, 16), torch.randn(2, 3, 16))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        rnnt_amd.joint_rnnt_loss(torch.randn(2, 5, 16), torch.randn(2, 3, 16), torch.randn(8, 16),
+                                 torch.randn(8), torch.zeros(2, 2, dtype=torch.int32),
+                                 torch.tensor([5, 4], dtype=torch.int32),
+                                 torch.tensor([2, 1], dtype=torch.int32))
+
+
+def test_rnnt_loss_argument_checks_match_torchaudio_style():
+    logits = torch.randn(2, 5, 3, 8)
+    tg = torch.zeros(2, 2, dtype=torch.int32)
+    ll = torch.tensor([5, 4], dtype=torch.int32)
+    tl = torch.tensor([2, 1], dtype=torch.int32)
+    with pytest.raises(ValueError):
+        rnnt_amd.rnnt_loss(logits, tg, ll, tl, reduction="avg")
+    with pytest.raises(RuntimeError, match="int32"):
+        rnnt_amd.rnnt_loss(logits, tg.long(), ll, tl)
+    with pytest.raises(RuntimeError, match="int32"):
+        rnnt_amd.rnnt_loss(logits, tg, ll.long(), tl)
+    with pytest.raises(RuntimeError, match="4 dimensions"):
+        rnnt_amd.rnnt_loss(logits[0], tg, ll, tl)
+    with pytest.raises(RuntimeError, match="float32"):
+        rnnt_amd.rnnt_loss(logits.double(), tg, ll, tl)
+    with pytest.raises(RuntimeError, match="blank"):
+        rnnt_amd.rnnt_loss(logits, tg, ll, tl, blank=8)
+    with pytest.raises(RuntimeError, match="input length mismatch"):
+        rnnt_amd.rnnt_loss(logits, tg, torch.tensor([4, 4], dtype=torch.int32), tl)
+    with pytest.raises(RuntimeError, match="output length mismatch"):
+        rnnt_amd.rnnt_loss(logits, tg, ll, torch.tensor([1, 1], dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="batch"):
+        rnnt_amd.rnnt_loss(logits, tg[:1], ll, tl)
+    with pytest.raises(NotImplementedError):
+        rnnt_amd.joint_rnnt_loss(torch.randn(2, 5, 16), torch.randn(2, 3, 16), torch.randn(8, 16),
+                                 torch.randn(8), tg, ll, tl, reduction="none")
+
+
+def test_model_container_interface():
+    """RNNTModel(predictor, encoder, joint) / .device / .greedy_decode (reference model.py:7-139)."""
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv1d(4, 8, 1)
+
+        def forward(self, x):
+            return self.c(x)
+
+        def calc_output_lens(self, lens):
+            return lens
+
+    class Pred(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.e = torch.nn.Embedding(6, 8)
+
+        def forward(self, ids):
+            return self.e(ids)
+
+    torch.manual_seed(0)
+    m = rnnt_amd.RNNTModel(Pred(), Enc(), rnnt_amd.JointNetwork(-1, -1, 8, 6))
+    assert m.device.type == "cpu"
+    assert sorted(dict(m.named_children())) == ["encoder", "joint", "predictor"]
+    toks = m.greedy_decode(torch.randn(1, 4, 7), torch.tensor([7]), max_length=5)
+    assert isinstance(toks, list) and len(toks) <= 4 and all(0 <= t < 5 for t in toks)
+
+
+def test_padding_helper_keeps_zero_probability_columns():
+    from rnnt_amd.functional import _pad_hv
+    enc, pred = torch.randn(1, 2, 6), torch.randn(1, 2, 6)
+    W, b = torch.randn(5, 6), torch.randn(5)
+    e, p, Wp, bp, H, V = _pad_hv(enc, pred, W, b)
+    assert e.shape[-1] == 8 and Wp.shape == (8, 8) and (H, V) == (6, 5)
+    assert (Wp[5:] == 0).all() and (Wp[:, 6:] == 0).all() and (bp[5:] < -1e29).all()
