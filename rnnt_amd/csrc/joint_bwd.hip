@@ -29,29 +29,30 @@ typedef __attribute__((address_space(3))) void *lds_void_ptr;
 #define DH_BT 8
 #define DH_BU 16
 
-#define DH_KC 8                                   // vocabulary entries (k) per staged chunk
-#define DH_NBUF 4                                 // LDS ring depth
-#define DH_BF (DH_KC * 512)                       // floats of the W slice of a chunk (16 KiB)
-#define DH_SLOTF (DH_BF + 4 * 256)                // + 4 M-tiles of G fragments (4 KiB)
-#define DH_REDF (4 * 64 * 33)                     // cross-wave dPred reduction scratch
-
 // dHidden GEMM: dHidden[c,:] = G[c,:] @ W   (M = 128 cells = 8 t x 16 u of one utterance,
-// K = V, N = 512 columns of H per workgroup).  8 waves = 2 (M) x 4 (N), wave tile 64 x 128
-// (8 accumulator tiles).  Same machinery as the forward kernel: both operands go HBM/L2 -> LDS
-// by LDS-DMA into a DH_NBUF-deep ring two chunks ahead (W: 8 rows x 2 KiB; G: one 1 KiB
-// fragment-ordered piece per 32-cell M-tile, gathered with per-lane source addresses),
-// fragments are 16-byte LDS reads issued right after the MFMAs that consumed the previous
-// ones, counted vmcnt + one s_barrier per chunk.  No VALU work in the loop: G was produced by
-// k_make_g (cells outside the lattice are zero rows; tile rows outside [T,U1] read the zero
-// padding row).
-// grid (n_ublk, n_ttile, B * n_hblk).
-__global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float smem[DH_NBUF * DH_SLOTF + DH_REDF];
-    float(*s_red)[64][33] = (float(*)[64][33])(smem + DH_NBUF * DH_SLOTF);
+// K = V, N = 512 columns of H per workgroup), then dPre = dHidden * (1 - hidden^2) reduced over
+// the tile's 16 u (-> dEnc partial) and 8 t (-> dPred partial).
+//
+// Same skeleton as k_dw (the one that measured best): 4 waves, one per SIMD, 2 (M) x 2 (N);
+// each wave owns 64 cells x 256 columns = 16 accumulator tiles (256 AGPRs); operands go
+// straight HBM/L2 -> VGPR, one 8-wide chunk (64 MFMAs) ahead, with unconditional loads (exact
+// vmcnt counting), no LDS, no barrier, no VALU in the main loop.  A lane's 16-byte G load is 4
+// consecutive k of its cell (k order inside the 8-wide chunk is a free permutation: lanes 0-31
+// take k0..k0+3, lanes 32-63 k0+4..k0+7); a 16-byte W load is 4 interleaved N tiles.
+// G was produced by k_make_g (cells outside the lattice are zero rows; tile rows outside
+// [T,U1] read the zero padding row).  grid (n_ublk, n_ttile, B * n_hblk).
+struct DhChunk {
+    f32x4 x[2];     // G slices of the two M tiles
+    f32x4 w[4][2];  // W rows k0+4*half+s, two 128-column groups
+};
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+__global__ __launch_bounds__(256, 1) void k_dhidden(JointBwdArgs a)
+{
+    __shared__ float s_red[2][64][65];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y;
@@ -59,157 +60,140 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
     const int Tb = a.logit_lens[b];
     const int t0 = tt * DH_BT, u0 = ub * DH_BU;
     if (t0 >= Tb) return;  // workgroup-uniform
-    const int ncol0 = hb * 512 + wn * 128;
-    const int col = ncol0 + 4 * i;
-    const bool colok = col < H;
-    const bool wave_on = ncol0 < H;
+    const int ncol0 = hb * 512 + wn * 256;
+    const int colg[2] = {ncol0 + 4 * i, ncol0 + 128 + 4 * i};
+    const bool colok[2] = {colg[0] < H, colg[1] < H};
     const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0, hidden == 0
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][8];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 8; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
 
     {
-        const int VK = (V + DH_KC - 1) / DH_KC;
-        // ---- DMA sources.  G piece of M-tile `wave` (waves 0-3): lane (i,half) fetches the
-        // 16 bytes G[cell(row wave*32+i)][k0 + 4*half ..]; that is already the MFMA A-fragment
-        // order, so the LDS image is lane-linear.
-        const float *gsrc = nullptr;
-        if (wave < 4) {
-            const int row = wave * 32 + i;
+        const int VK = (V + 7) / 8, last = VK - 1;
+        // V % 8 == 4: in the last chunk lanes 32-63 would start at k >= V; they step back 4
+        // (valid addresses) and their G values are zeroed
+        const bool kill = ((V & 7) != 0) && half == 1;
+        const int back = kill ? 4 : 0;
+        const float *gptr[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = wm * 64 + mt * 32 + i;
             const int t = t0 + (row >> 4), u = u0 + (row & 15);
             const long cell = (t < T && u < U1) ? ((long)b * T + t) * U1 + u : zero_row;
-            gsrc = a.logits + cell * V + 4 * half;
+            gptr[mt] = a.logits + cell * V + 4 * half;
         }
-        // W slice: 16 pieces of 1 KiB per chunk, piece x = wave*2 + j: row x>>1, half-row x&1
-        const float *zsrc = a.hidden + zero_row * H;          // >= 16 B of zeros for k >= V
-        const int n_own = wave < 4 ? 3 : 2;                   // VMEM ops this wave issues per chunk
-        auto dma = [&](int c8, int slot) {
-            float *dst = smem + slot * DH_SLOTF;
-            const int k0 = c8 * DH_KC;
+        // columns beyond H (last column block) read column 0: they feed unstored accumulators
+        const float *wptr[2] = {a.W + (long)(4 * half) * H + (colok[0] ? colg[0] : 0),
+                                a.W + (long)(4 * half) * H + (colok[1] ? colg[1] : 0)};
+        auto load = [&](DhChunk &c, int c8) {
+            const int cc = c8 < last ? c8 : last;
+            const int k0 = 8 * cc - (cc == last ? back : 0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int x = wave * 2 + j, row = x >> 1, hx = x & 1;
-                const int cx = min(hb * 512 + hx * 256 + 4 * lane, H - 4);
-                const float *src = (k0 + row < V) ? a.W + (long)(k0 + row) * H + cx : zsrc;
-                __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)(dst + row * 512 + hx * 256), 16,
-                                                 0, 0);
-            }
-            if (wave < 4) {
-                // V % 8 == 4 tail: lanes 32-63 would start at k >= V; they re-read k0 (finite)
-                // and meet zero W rows, contributing 0
-                const int kk = (k0 + 4 * half < V) ? k0 : k0 - 4;
-                __builtin_amdgcn_global_load_lds(gsrc + kk, (lds_void_ptr)(dst + DH_BF + wave * 256),
-                                                 16, 0, 0);
-            }
+            for (int mt = 0; mt < 2; ++mt) c.x[mt] = *(const f32x4 *)(gptr[mt] + k0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    c.w[s_][g] = *(const f32x4 *)(wptr[g] + (long)(k0 + s_) * H);
         };
-        const int a_off = DH_BF + (wm * 2) * 256 + 4 * lane;           // + mt*256
-        const int b_off = (4 * half) * 512 + wn * 128 + 4 * i;         // + s*512
-        f32x4 x4[2], w4[4];
-        dma(0, 0);
-        if (VK > 1) dma(1, 1);
-        if (VK > 2) dma(2, 2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        auto compute = [&](const DhChunk &c, bool zero_hi) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) x4[mt] = *(const f32x4 *)(smem + a_off + mt * 256);
+            for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) w4[s_] = *(const f32x4 *)(smem + b_off + s_ * 512);
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float gv = zero_hi ? 0.f : c.x[mt][s_];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                gv, c.w[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
+                }
+        };
+        DhChunk nxt;
+        load(nxt, 0);
         for (int c8 = 0; c8 < VK; ++c8) {
-            // retire own DMA of chunk c8+1 (issued two iterations ago); the newest stays in flight
-            if (c8 + 2 >= VK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing newer
-            else if (n_own == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            const DhChunk cur = nxt;
+            load(nxt, c8 + 1);  // one chunk (64 MFMAs, ~4096 matrix-pipe cycles) ahead
             __builtin_amdgcn_sched_barrier(0);
-            if (c8 + 3 < VK) dma(c8 + 3, (c8 + 3) & (DH_NBUF - 1));
+            compute(cur, kill && c8 == last);
             __builtin_amdgcn_sched_barrier(0);
-            // fragments of chunk c8+1 (clamped at the end: re-reads the last chunk, unused)
-            const float *nx = smem + ((c8 + 1 < VK ? c8 + 1 : c8) & (DH_NBUF - 1)) * DH_SLOTF;
-            float g[2][4];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) g[mt][s_] = x4[mt][s_];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) x4[mt] = *(const f32x4 *)(nx + a_off + mt * 256);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[mt][s_], w4[s_][q],
-                                                                          acc[mt][q], 0, 0, 0);
-                w4[s_] = *(const f32x4 *)(nx + b_off + s_ * 512);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
-    float psum[8][4];
+    float psum[8][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) psum[k][q] = 0.f;
+        for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
 
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
-    if (wave_on) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-                const int tl = wm * 4 + mt * 2 + rh;
-                const int t = t0 + tl;
-                const bool tok = t < Tb;
-                float esum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int rh = 0; rh < 2; ++rh) {
+            const int tl = wm * 4 + mt * 2 + rh;
+            const int t = t0 + tl;
+            const bool tok = t < Tb;
+            float esum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r7 = 0; r7 < 8; ++r7) {
-                    const int ul = 8 * (r7 >> 2) + 4 * half + (r7 & 3);
-                    const int u = u0 + ul;
-                    const bool ok = tok && u < U1 && colok;
+            for (int r7 = 0; r7 < 8; ++r7) {
+                const int ul = 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+                const int u = u0 + ul;
+                const bool rok = tok && u < U1;
+                const float *hrow = a.hidden + (((long)b * T + (rok ? t : 0)) * U1 + (rok ? u : 0)) * H;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const bool ok = rok && colok[g];
                     f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) h4 = *(const f32x4 *)(a.hidden + (((long)b * T + t) * U1 + u) * H + col);
+                    if (ok) h4 = *(const f32x4 *)(hrow + colg[g]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float d = ok ? acc[mt][q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
-                        esum[q] += d;
-                        psum[r7][q] += d;
+                        const float d =
+                            ok ? acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
+                        esum[g * 4 + q] += d;
+                        psum[r7][g * 4 + q] += d;
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
-                if (half == 0 && tok && colok) {
-                    f32x4 o = {esum[0], esum[1], esum[2], esum[3]};
-                    *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + col) = o;
-                }
             }
-    }
-    __syncthreads();  // every wave is past its last ring read before s_red (same array) is used
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
+            if (half == 0 && tok) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
+                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
+                    }
+            }
+        }
     if (wm == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s_red[wn][lane][k * 4 + q] = psum[k][q];
+            for (int q = 0; q < 8; ++q) s_red[wn][lane][k * 8 + q] = psum[k][q];
     }
     __syncthreads();
-    if (wm == 0 && wave_on && colok) {
+    if (wm == 0) {
 #pragma unroll
         for (int r7 = 0; r7 < 8; ++r7) {
             const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
             if (u < U1) {
-                f32x4 o;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = psum[r7][q] + s_red[wn][lane][r7 * 4 + q];
-                *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + col) = o;
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            o[q] = psum[r7][g * 4 + q] + s_red[wn][lane][r7 * 8 + g * 4 + q];
+                        *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + colg[g]) = o;
+                    }
             }
         }
     }
@@ -253,7 +237,7 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 {
     const int n_hblk = (a.H + 511) / 512;
     dim3 grid(a.n_ublk, a.n_ttile, a.B * n_hblk);
-    hipLaunchKernelGGL(k_dhidden, grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_dhidden, grid, dim3(256), 0, st, a);
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,
                        a.slab_enc, a.logit_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);
