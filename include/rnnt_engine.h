@@ -121,7 +121,7 @@ int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3]
  */
 typedef struct rnnt_engine_ws_layout {
     size_t logits, hidden, denom_s, lpb_s, lpe_s, alpha_s, beta_s, coef, wpack, enc_copy;
-    size_t slab_enc, slab_pred, slab_w, slab_b, total, rows_pad;
+    size_t slab_enc, slab_pred, slab_w, slab_b, counters, total, rows_pad;
     int n_ublk, n_ttile, n_split, D;
 } rnnt_engine_ws_layout;
 

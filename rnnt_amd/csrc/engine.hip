@@ -61,7 +61,7 @@ void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
     L->rows_pad = rows_pad;
     L->D = (int)D;
     L->n_ublk = (U1 + 15) / 16;
-    L->n_ttile = (T + 7) / 8;
+    L->n_ttile = (T + 3) / 4;
     L->n_split = dw_splits(B, T, H, V);
     size_t o = 0;
     L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
@@ -78,6 +78,7 @@ void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
     L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
     L->slab_w = o;   o += align_up((size_t)L->n_split * V * H * 4);
     L->slab_b = o;   o += align_up((size_t)L->n_split * V * 4);
+    L->counters = o; o += 256;
     L->total = o;
 }
 
@@ -101,6 +102,19 @@ void resolve_enc(const void *enc, const int64_t s[3], int B, int T, int H, float
         launch_copy_enc((const float *)enc, s[0], s[1], s[2], copy_buf, B, T, H, st);
         *out = copy_buf; *sb = (long)T * H; *st_ = H;
     }
+}
+
+int device_cus()
+{
+    static thread_local int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
 }
 
 enum { ST_FWD = 1, ST_LATTICE = 2, ST_COEF = 4, ST_DH = 8, ST_DW = 16, ST_ALL = 31 };
@@ -140,11 +154,24 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     const float *encp; long esb, est;
     resolve_enc(enc, enc_strides, B, T, H, (float *)(ws + L.enc_copy), st, &encp, &esb, &est);
 
+    JointBwdArgs g;
+    g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred;
+    g.W = (const float *)W; g.logits = logits; g.coef = coef; g.logit_lens = logit_lens;
+    g.hidden = (float *)(ws + L.hidden); g.rows_pad = (long)L.rows_pad;
+    g.slab_enc = (float *)(ws + L.slab_enc); g.slab_pred = (float *)(ws + L.slab_pred);
+    g.slab_w = (float *)(ws + L.slab_w); g.slab_b = (float *)(ws + L.slab_b);
+    g.grad_enc = (float *)grad_enc; g.grad_pred = (float *)grad_pred;
+    g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
+    g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
+    g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
+    g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags;
+
     if (stages & ST_FWD) {
+        launch_make_hidden(g, st);  // A operand of the forward GEMM and of both backward GEMMs
         launch_pack_w_fwd((const float *)W, wpack, H, V, st);
         JointFwdArgs f;
         f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred;
-        f.wpack = wpack; f.bias = (const float *)bias; f.targets = targets;
+        f.wpack = wpack; f.hidden = (g_flags & 8) ? nullptr : g.hidden; f.bias = (const float *)bias; f.targets = targets;
         f.logit_lens = logit_lens; f.target_lens = target_lens; f.logits = logits;
         f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
         f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = g_flags; f.debug = g_debug;
@@ -155,21 +182,8 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     if (stages & ST_COEF)
         launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                     B, T, U1, L.D, grad_scale, st);
-    if (stages & (ST_COEF | ST_DH | ST_DW)) {
-        JointBwdArgs g;
-        g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred;
-        g.W = (const float *)W; g.logits = logits; g.coef = coef; g.logit_lens = logit_lens;
-        g.hidden = (float *)(ws + L.hidden); g.rows_pad = (long)L.rows_pad;
-        g.slab_enc = (float *)(ws + L.slab_enc); g.slab_pred = (float *)(ws + L.slab_pred);
-        g.slab_w = (float *)(ws + L.slab_w); g.slab_b = (float *)(ws + L.slab_b);
-        g.grad_enc = (float *)grad_enc; g.grad_pred = (float *)grad_pred;
-        g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
-        g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
-        g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
-        if (stages & ST_COEF) {  // operand producers of the two backward GEMMs
-            launch_make_hidden(g, st);
-            launch_make_g(g, st);
-        }
+    {
+        if (stages & ST_COEF) launch_make_g(g, st);  // logits -> G in place
         if (stages & ST_DH) launch_dhidden(g, st);
         if (stages & ST_DW) launch_dw(g, st);
     }

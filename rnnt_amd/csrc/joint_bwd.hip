@@ -29,171 +29,173 @@ typedef __attribute__((address_space(3))) void *lds_void_ptr;
 #define DH_BT 8
 #define DH_BU 16
 
-// dHidden GEMM: dHidden[c,:] = G[c,:] @ W   (M = 128 cells = 8 t x 16 u of one utterance,
-// K = V, N = 512 columns of H per workgroup), then dPre = dHidden * (1 - hidden^2) reduced over
-// the tile's 16 u (-> dEnc partial) and 8 t (-> dPred partial).
+// dHidden GEMM: dHidden[c,:] = G[c,:] @ W   (K = V), then dPre = dHidden * (1 - hidden^2)
+// reduced over the item's 16 u (-> dEnc partial slab) and its 4 t (-> dPred partial slab).
 //
-// Same skeleton as k_dw (the one that measured best): 4 waves, one per SIMD, 2 (M) x 2 (N);
-// each wave owns 64 cells x 256 columns = 16 accumulator tiles (256 AGPRs); operands go
-// straight HBM/L2 -> VGPR, one 8-wide chunk (64 MFMAs) ahead, with unconditional loads (exact
-// vmcnt counting), no LDS, no barrier, no VALU in the main loop.  A lane's 16-byte G load is 4
-// consecutive k of its cell (k order inside the 8-wide chunk is a free permutation: lanes 0-31
-// take k0..k0+3, lanes 32-63 k0+4..k0+7); a 16-byte W load is 4 interleaved N tiles.
-// G was produced by k_make_g (cells outside the lattice are zero rows; tile rows outside
-// [T,U1] read the zero padding row).  grid (n_ublk, n_ttile, B * n_hblk).
-struct DhChunk {
-    f32x4 x[2];     // G slices of the two M tiles
-    f32x4 w[4][2];  // W rows k0+4*half+s, two 128-column groups
+// Persistent, fully independent waves.  Measured facts behind this shape: the
+// SIMD arbitrates oldest-first, so two co-resident waves do not interleave — the older runs
+// at its own pace and the younger fills its bubbles; any barrier / end-of-workgroup join then
+// leaves a wave slot idle while its partner finishes alone.  So here NOTHING joins waves:
+//   * work item = 64 cells (4 t x 16 u of one utterance) x 128 columns of H: 8 accumulator
+//     tiles (128 registers) -> two waves per SIMD fit, and one wave's epilogue (hidden loads,
+//     reductions, slab stores) overlaps its SIMD partner's MFMA stream;
+//   * each wave pulls items from a global atomic counter until none are left (perfect balance,
+//     no workgroup tail); items are ordered column-block fastest, so the waves that share a G
+//     tile run at about the same time and meet in L2;
+//   * operands go straight HBM/L2 -> VGPR (register-destination loads cost the matrix pipe
+//     nothing to issue; an LDS-DMA piece costs ~60 cycles), two 8-wide k chunks ahead, every
+//     load unconditional; no LDS, no barrier, no VALU in the main loop.
+// The item's reductions are in-wave: dEnc sums a lane's 8 rows + one cross-half shuffle, dPred
+// sums over the 4 (M-tile, row-half) groups in-lane.
+#define PW_BT 4
+struct PwChunk {
+    f32x4 x[2];  // G slices (4 consecutive k) of the two M tiles
+    f32x4 w[4];  // W rows k0+4*half+s, columns n0+4j..4j+3
 };
 
-__global__ __launch_bounds__(256, 1) void k_dhidden(JointBwdArgs a)
+__global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
 {
-    __shared__ float s_red[2][64][65];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int lane = threadIdx.x & 63;
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
-    const int ub = blockIdx.x, tt = blockIdx.y;
-    const int b = blockIdx.z % a.B, hb = blockIdx.z / a.B;
-    const int Tb = a.logit_lens[b];
-    const int t0 = tt * DH_BT, u0 = ub * DH_BU;
-    if (t0 >= Tb) return;  // workgroup-uniform
-    const int ncol0 = hb * 512 + wn * 256;
-    const int colg[2] = {ncol0 + 4 * i, ncol0 + 128 + 4 * i};
-    const bool colok[2] = {colg[0] < H, colg[1] < H};
-    const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0, hidden == 0
+    const int n_cb = (H + 127) / 128, n_ub = (U1 + DH_BU - 1) / DH_BU, n_tt = (T + PW_BT - 1) / PW_BT;
+    const long total = (long)a.B * n_tt * n_ub * n_cb;
+    const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0
+    // V % 8 == 4: in the last chunk lanes 32-63 would start at k >= V; they step back 4
+    // (valid addresses) and their G values are zeroed
+    const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
 
-    f32x16 acc[2][8];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+    for (;;) {
+        long item = 0;
+        if (lane == 0) item = (long)atomicAdd(a.counter, 1u);
+        item = __builtin_amdgcn_readfirstlane((int)item);
+        if (item >= total) break;
+        const int cb = (int)(item % n_cb);
+        long r_ = item / n_cb;
+        const int ub = (int)(r_ % n_ub); r_ /= n_ub;
+        const int tt = (int)(r_ % n_tt);
+        const int b = (int)(r_ / n_tt);
+        const int Tb = a.logit_lens[b];
+        const int t0 = tt * PW_BT, u0 = ub * DH_BU;
+        if (t0 >= Tb) continue;  // wave-uniform
+        const int col = cb * 128 + 4 * i;
+        const bool colok = col < H;
 
-    {
-        const int VK = (V + 7) / 8, last = VK - 1;
-        // V % 8 == 4: in the last chunk lanes 32-63 would start at k >= V; they step back 4
-        // (valid addresses) and their G values are zeroed
-        const bool kill = ((V & 7) != 0) && half == 1;
-        const int back = kill ? 4 : 0;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+
         const float *gptr[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int row = wm * 64 + mt * 32 + i;
+            const int row = mt * 32 + i;
             const int t = t0 + (row >> 4), u = u0 + (row & 15);
             const long cell = (t < T && u < U1) ? ((long)b * T + t) * U1 + u : zero_row;
             gptr[mt] = a.logits + cell * V + 4 * half;
         }
         // columns beyond H (last column block) read column 0: they feed unstored accumulators
-        const float *wptr[2] = {a.W + (long)(4 * half) * H + (colok[0] ? colg[0] : 0),
-                                a.W + (long)(4 * half) * H + (colok[1] ? colg[1] : 0)};
-        auto load = [&](DhChunk &c, int c8) {
-            const int cc = c8 < last ? c8 : last;
+        const float *wptr = a.W + (long)(4 * half) * H + (colok ? col : 0);
+        // Main loop: 32 MFMAs per 8-wide k chunk, operands two chunks ahead in two register sets
+        // (copy, refill, then compute: refilling a set right behind its own MFMAs, or rotating
+        // three sets, measured slower / spilled).  The k order of a dot product is free: every
+        // item starts at its own chunk (`rot`) so the waves do not walk W and the 4 KiB-strided
+        // G rows in step.  V % 8 == 4: in the last chunk lanes 32-63 step back 4 (valid
+        // addresses) and their G values are zeroed.
+        const int VK = (V + 7) / 8, last = VK - 1;
+        const bool kill = ((V & 7) != 0) && half == 1;
+        const int back = kill ? 4 : 0;
+        const int rot = (int)((item * 37) % VK);
+        auto chunk_of = [&](int c8) { int cc = c8 + rot; cc -= cc >= VK ? VK : 0; cc -= cc >= VK ? VK : 0; return cc; };
+        auto load = [&](PwChunk &c, int c8) {
+            const int cc = chunk_of(c8);
             const int k0 = 8 * cc - (cc == last ? back : 0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) c.x[mt] = *(const f32x4 *)(gptr[mt] + k0);
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    c.w[s_][g] = *(const f32x4 *)(wptr[g] + (long)(k0 + s_) * H);
+            for (int s_ = 0; s_ < 4; ++s_) c.w[s_] = *(const f32x4 *)(wptr + (long)(k0 + s_) * H);
         };
-        auto compute = [&](const DhChunk &c, bool zero_hi) {
+        auto compute = [&](const PwChunk &c, bool zero_hi) {
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const float gv = zero_hi ? 0.f : c.x[mt][s_];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                gv, c.w[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q)
+                        acc[mt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, c.w[s_][q], acc[mt][q],
+                                                                          0, 0, 0);
                 }
         };
-        DhChunk nxt;
-        load(nxt, 0);
-        for (int c8 = 0; c8 < VK; ++c8) {
-            const DhChunk cur = nxt;
-            load(nxt, c8 + 1);  // one chunk (64 MFMAs, ~4096 matrix-pipe cycles) ahead
-            __builtin_amdgcn_sched_barrier(0);
-            compute(cur, kill && c8 == last);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
-    float psum[8][8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
-
-    const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int rh = 0; rh < 2; ++rh) {
-            const int tl = wm * 4 + mt * 2 + rh;
-            const int t = t0 + tl;
-            const bool tok = t < Tb;
-            float esum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r7 = 0; r7 < 8; ++r7) {
-                const int ul = 8 * (r7 >> 2) + 4 * half + (r7 & 3);
-                const int u = u0 + ul;
-                const bool rok = tok && u < U1;
-                const float *hrow = a.hidden + (((long)b * T + (rok ? t : 0)) * U1 + (rok ? u : 0)) * H;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const bool ok = rok && colok[g];
-                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) h4 = *(const f32x4 *)(hrow + colg[g]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float d =
-                            ok ? acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
-                        esum[g * 4 + q] += d;
-                        psum[r7][g * 4 + q] += d;
-                    }
-                }
+        const bool xp_noepi = (a.flags & 4) != 0;  // experiment switch
+        PwChunk r0, r1;
+        load(r0, 0);
+        load(r1, 1);
+        for (int c8 = 0; c8 < VK; c8 += 2) {
+            {
+                const PwChunk cur = r0;
+                load(r0, c8 + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(cur, kill && chunk_of(c8) == last);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
-            if (half == 0 && tok) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (colok[g]) {
-                        f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
-                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
-                    }
+            if (c8 + 1 < VK) {
+                const PwChunk cur = r1;
+                load(r1, c8 + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(cur, kill && chunk_of(c8 + 1) == last);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-    if (wm == 1) {
+
+        if (xp_noepi) {
+            if (acc[0][0][0] == 12345.f) a.slab_enc[0] = acc[1][3][7];
+            continue;
+        }
+        // ---- epilogue (in-wave): dPre = dHidden * (1 - hidden^2); sum over u and over t
+        float psum[8][4];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s_red[wn][lane][k * 8 + q] = psum[k][q];
-    }
-    __syncthreads();
-    if (wm == 0) {
+            for (int q = 0; q < 4; ++q) psum[k][q] = 0.f;
 #pragma unroll
-        for (int r7 = 0; r7 < 8; ++r7) {
-            const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
-            if (u < U1) {
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (colok[g]) {
-                        f32x4 o;
+            for (int rh = 0; rh < 2; ++rh) {
+                const int t = t0 + mt * 2 + rh;
+                const bool tok = t < Tb;
+                float esum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            o[q] = psum[r7][g * 4 + q] + s_red[wn][lane][r7 * 8 + g * 4 + q];
-                        *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + colg[g]) = o;
+                for (int r7 = 0; r7 < 8; ++r7) {
+                    const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+                    const bool ok = tok && u < U1 && colok;
+                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) h4 = *(const f32x4 *)(a.hidden + (((long)b * T + t) * U1 + u) * H + col);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d = ok ? acc[mt][q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
+                        esum[q] += d;
+                        psum[r7][q] += d;
                     }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
+                if (half == 0 && tok && colok) {
+                    f32x4 o = {esum[0], esum[1], esum[2], esum[3]};
+                    *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + col) = o;
+                }
+            }
+        if (colok) {
+#pragma unroll
+            for (int r7 = 0; r7 < 8; ++r7) {
+                const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+                if (u < U1) {
+                    f32x4 o = {psum[r7][0], psum[r7][1], psum[r7][2], psum[r7][3]};
+                    *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + col) = o;
+                }
             }
         }
     }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ s
     const long n = (long)B * U1 * H4;
     if (idx >= n) return;
     const int b = (int)(idx / ((long)U1 * H4));
-    const int ntt = (logit_lens[b] + DH_BT - 1) / DH_BT;
+    const int ntt = (logit_lens[b] + PW_BT - 1) / PW_BT;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < ntt; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
     ((f32x4 *)out)[idx] = s;
@@ -235,9 +237,8 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ s
 
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 {
-    const int n_hblk = (a.H + 511) / 512;
-    dim3 grid(a.n_ublk, a.n_ttile, a.B * n_hblk);
-    hipLaunchKernelGGL(k_dhidden, grid, dim3(256), 0, st, a);
+    (void)hipMemsetAsync(a.counter, 0, 16, st);  // work-item counter of the persistent waves
+    hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a);
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,
                        a.slab_enc, a.logit_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);

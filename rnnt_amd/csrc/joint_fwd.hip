@@ -100,7 +100,11 @@ typedef __attribute__((address_space(3))) void *lds_void_ptr;
 // consumer can be scheduled above the wait (cdna_hip_programming.md §5.7, form (ii)).
 __device__ __forceinline__ void asm_load16(f32x4 &dst, const float *ptr)
 {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+    // "+v": (1) the destination cannot share registers with the address pair — an overlapping
+    // vdst/vaddr returned garbage whenever the access straddled a 2 GiB boundary; (2) the
+    // loop-carried variable keeps ONE physical register, so hipcc has no reason to copy the
+    // still-pending destination at the loop back-edge (with "=v" it did, reading stale data).
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(ptr) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void vm_wait(f32x4 &e, f32x4 &p)
@@ -129,6 +133,7 @@ __device__ __forceinline__ void vm_wait(f32x4 &e, f32x4 &p)
 // CUs do not all walk the same 16 KB of wpack at once.  W is zero-padded in wpack, tanh of any
 // finite input is finite, and address clamps keep every load in bounds, so no load in the
 // loop is conditional.
+template <bool USE_HID>  // true: erow points at the precomputed hidden row (no tanh, no pred)
 __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *prow,
                                              const f32x4 *wpass, int gvalid, int HK,
                                              long wstride, int H, int half, int rot, int wave,
@@ -158,19 +163,19 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
     int c1 = nextc(cc), c2 = nextc(c1);
     dma(cc, 0);
     dma(c1, 1);
-    f32x4 e, p;
+    f32x4 e = {0.f, 0.f, 0.f, 0.f}, p = {0.f, 0.f, 0.f, 0.f};
     asm_load16(e, erow + aoff(cc));
-    asm_load16(p, prow + aoff(cc));
+    if (!USE_HID) asm_load16(p, prow + aoff(cc));
     vm_wait<0>(e, p);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) w[q] = ldsb[roff + q * 64];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a_cur[s] = fast_tanh(e[s] + p[s]);
+    for (int s = 0; s < 4; ++s) a_cur[s] = USE_HID ? e[s] : fast_tanh(e[s] + p[s]);
     __builtin_amdgcn_sched_barrier(0);
     asm_load16(e, erow + aoff(c1));
-    asm_load16(p, prow + aoff(c1));
+    if (!USE_HID) asm_load16(p, prow + aoff(c1));
     __builtin_amdgcn_sched_barrier(0);
     dma(c2, 2);
     __builtin_amdgcn_sched_barrier(0);
@@ -187,7 +192,13 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
         const int a2 = aoff(ca);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (q < 4) a_nxt[q] = fast_tanh(e[q] + p[q]);
+            if (q < 4) {
+                if (USE_HID)  // an opaque move: without it hipcc aliases a_nxt to e, keeps the old
+                              // e live and rotates the PENDING new e through a copy at the back-edge
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(a_nxt[q]) : "v"(e[q]));
+                else
+                    a_nxt[q] = fast_tanh(e[q] + p[q]);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], w[q][s], acc[q], 0, 0, 0);
@@ -195,7 +206,7 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
             if (q == 3) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm_load16(e, erow + a2);
-                asm_load16(p, prow + a2);
+                if (!USE_HID) asm_load16(p, prow + a2);
                 __builtin_amdgcn_sched_barrier(0);
                 dma(cdma, slot_wr);
             }
@@ -229,7 +240,7 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
 #define STAMP(slot)
 #endif
 
-template <bool WITH_LOSS>
+template <bool WITH_LOSS, bool USE_HID>
 __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
 {
     // ALL LDS in one array (hipcc otherwise guards every ds_read with vmcnt(0) while an LDS-DMA
@@ -277,7 +288,10 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     // this lane's A row: cell -> (t,u) -> 16-byte slices of enc / pred
     const int crow = min(m0 + wm * 32 + i, ncell - 1);
     const int trow = crow / U1, urow = crow - trow * U1;
-    const float *erow = a.enc + (long)b * a.enc_sb + (long)trow * a.enc_st + 4 * half;
+    // fused path: A comes from the hidden buffer k_make_hidden filled (the backward GEMMs need
+    // it anyway), so the loop carries no tanh; the plain joint computes tanh in-loop
+    const float *erow = USE_HID ? a.hidden + ((long)b * T * U1 + crow) * H + 4 * half
+                                  : a.enc + (long)b * a.enc_sb + (long)trow * a.enc_st + 4 * half;
     const float *prow = a.pred + ((long)b * U1 + urow) * H + 4 * half;
     const int HK = (H + 7) / 8, NG = (V + 127) / 128;
     const long wstride = (long)NG * 256;  // float4 per 8-wide k chunk
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
         const int gvalid = min(4, NG - pass * 4);
         STAMP(1 + 2 * (pass & 1));
-        fwd_mainloop(erow, prow, wpass, gvalid, HK, wstride, H, half, rot, wave, lane, wn, s_b, acc);
+        fwd_mainloop<USE_HID>(erow, prow, wpass, gvalid, HK, wstride, H, half, rot, wave, lane, wn,
+                                s_b, acc);
         STAMP(2 + 2 * (pass & 1));
 
         // ---- epilogue: store logits, fold this pass into the running row log-sum-exp
@@ -411,10 +426,12 @@ void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
 {
     const int tiles = (int)(((long)a.T * a.U1 + FWD_ROWS - 1) / FWD_ROWS);
     dim3 grid(tiles, a.B), block(FWD_THREADS);
-    if (a.denom_s)
-        hipLaunchKernelGGL(k_joint_fwd<true>, grid, block, 0, st, a);
+    if (a.denom_s && a.hidden)
+        hipLaunchKernelGGL((k_joint_fwd<true, true>), grid, block, 0, st, a);
+    else if (a.denom_s)
+        hipLaunchKernelGGL((k_joint_fwd<true, false>), grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL(k_joint_fwd<false>, grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_joint_fwd<false, false>), grid, block, 0, st, a);
 }
 
 // Diagnostic: resident workgroups per CU the runtime predicts for the forward kernel.
@@ -422,8 +439,8 @@ int fwd_occupancy(int with_loss)
 {
     int n = -1;
     if (with_loss)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_joint_fwd<true>, FWD_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_joint_fwd<true, true>, FWD_THREADS, 0);
     else
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_joint_fwd<false>, FWD_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_joint_fwd<false, false>, FWD_THREADS, 0);
     return n;
 }

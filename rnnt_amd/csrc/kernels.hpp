@@ -23,6 +23,7 @@ struct JointFwdArgs {
     long enc_sb, enc_st;
     const float *pred;  // [B,U1,H] contiguous
     const float *wpack; // packed W (pack_w_fwd)
+    const float *hidden; // [rows,H] tanh(enc+pred) from k_make_hidden (fused path), else NULL
     const float *bias;  // [V]
     const int32_t *targets, *logit_lens, *target_lens;  // all NULL for the plain joint
     float *logits;      // [B,T,U1,V]
@@ -55,6 +56,9 @@ struct JointBwdArgs {
     float *grad_enc, *grad_pred, *grad_W, *grad_bias;
     int B, T, U1, H, V, blank;
     int n_ublk, n_ttile, n_split;
+    unsigned *counter;  // 16 zeroed bytes: work-item counter of the persistent kernels
+    int n_cu;           // compute units (grid size of the persistent kernels)
+    int flags;          // experiment switches (rnnt_engine_set_flags)
 };
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);

@@ -31,7 +31,7 @@ EXPORTS = (
 class WsLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "logits", "hidden", "denom_s", "lpb_s", "lpe_s", "alpha_s", "beta_s", "coef", "wpack",
-        "enc_copy", "slab_enc", "slab_pred", "slab_w", "slab_b", "total", "rows_pad")] + [
+        "enc_copy", "slab_enc", "slab_pred", "slab_w", "slab_b", "counters", "total", "rows_pad")] + [
         (n, ctypes.c_int) for n in ("n_ublk", "n_ttile", "n_split", "D")]
 
 

@@ -70,8 +70,8 @@ def test_layout_is_consistent(lib):
     from rnnt_amd import engine
     L = engine.layout(3, 17, 9, 64, 32)
     offs = [L.logits, L.hidden, L.denom_s, L.lpb_s, L.lpe_s, L.alpha_s, L.beta_s, L.coef, L.wpack,
-            L.enc_copy, L.slab_enc, L.slab_pred, L.slab_w, L.slab_b, L.total]
+            L.enc_copy, L.slab_enc, L.slab_pred, L.slab_w, L.slab_b, L.counters, L.total]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
-    assert L.D == 17 + 9 - 1 and L.n_ublk == 1 and L.n_ttile == 3
+    assert L.D == 17 + 9 - 1 and L.n_ublk == 1 and L.n_ttile == 5
     assert L.rows_pad % 16 == 0 and L.rows_pad > 3 * 17 * 9
     assert L.total == engine.workspace_bytes(3, 17, 9, 64, 32)

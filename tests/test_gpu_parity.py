@@ -198,6 +198,24 @@ def test_model_forward_matches_unfused(amd):
         assert_close_grad(k, g_fused[k].cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4)
 
 
+def test_midsize_long_lattice_loss_vs_oracle(amd):
+    """Long lattice at the BASELINE H and V (B=2,T=500,U=100,H=512,V=1024, ragged): per-utterance
+    costs of the fused path vs the fp64 oracle (loss only: the oracle's forward is OpenMP
+    parallel, its backward is not).  Catches errors that only show with many k-chunks, many
+    tiles and multi-GiB buffers (a register-aliasing bug in an inline-asm load did)."""
+    from oracle import cpu_oracle
+    d = make_inputs(2, 500, 100, 512, 1024, seed=5)
+    logits = cpu_oracle.joint_fwd(d["enc"], d["pred"], d["W"], d["bias"], dtype=np.float64)
+    ref, _ = cpu_oracle.rnnt_loss(logits, d["targets"], d["logit_lens"], d["target_lens"],
+                                  want_grad=False)
+    g = _dev(d)
+    outs = amd.engine.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"],
+                                         g["logit_lens"], g["target_lens"], 1023, 0.5)
+    assert_close_loss("costs", outs[0].cpu().numpy(), ref, rtol=1e-6)
+    for o in outs[1:]:
+        assert torch.isfinite(o).all()
+
+
 # ---------------------------------------------------------------- full-size properties
 def _full(amd, B, T, U, H, V, seed):
     d = make_inputs(B, T, U, H, V, seed, ragged=False)

@@ -1,0 +1,43 @@
+"""Diagnostic: closed-form cost check at cfg2 size, several runs, report every mismatch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests.helpers import make_inputs, lgamma_paths_cost
+from rnnt_amd import engine
+B, T, U, H, V = 32, 1000, 200, 512, 1024
+d = make_inputs(B, T, U, H, V, 2, ragged=False)
+d["W"] = np.zeros_like(d["W"])
+t = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+bias = d["bias"].astype(np.float64); lp = bias - np.log(np.exp(bias).sum())
+ref = np.array([lgamma_paths_cost(T, U, lp[V-1], lp[d["targets"][b]].sum()) for b in range(B)])
+for it in range(6):
+    engine.lib().rnnt_engine_set_flags(8 if it >= 4 else 0)  # runs 4,5: tanh-in-loop forward
+    outs = engine.joint_loss_fwd_bwd(t["enc"], t["pred"], t["W"], t["bias"], t["targets"], t["logit_lens"], t["target_lens"], V-1, 1.0/B)
+    torch.cuda.synchronize()
+    c = outs[0].cpu().numpy().astype(np.float64)
+    bad = np.nonzero(np.abs(c - ref) / ref > 1e-5)[0]
+    print("run", it, "bad utterances:", bad.tolist(), [(round(float(c[b]-ref[b]),3)) for b in bad[:6]])
+    if it == 1 and len(bad):
+        L = engine.layout(B, T, U+1, H, V)
+        ws = engine._workspaces[("cuda", 0)]
+        D = L.D
+        print("  workspace base mod 4GiB (GB):", (ws.data_ptr() % (1 << 32)) / 1e9, " logits bytes/utt (GB):", T*(U+1)*V*4/1e9)
+        get = lambda off, dt, n: ws[off:off + n * (8 if dt == torch.float64 else 4)].view(dt).view(B, D, U+1).cpu().numpy()
+        lpb, lpe, den = (get(o, torch.float32, B*D*(U+1)) for o in (L.lpb_s, L.lpe_s, L.denom_s))
+        be = get(L.beta_s, torch.float64, B*D*(U+1)); al = get(L.alpha_s, torch.float64, B*D*(U+1))
+        lse = np.log(np.exp(bias).sum())
+        hid = ws[L.hidden:L.hidden + L.rows_pad * H * 4].view(torch.float32).view(-1, H)
+        for b in bad[:2]:
+            hb = hid[b*T*(U+1):(b+1)*T*(U+1)]
+            nf = (~torch.isfinite(hb)).any(1).nonzero().flatten()
+            exp = torch.tanh(t["enc"][b].unsqueeze(1) + t["pred"][b].unsqueeze(0)).reshape(-1, H)
+            werr = ((hb - exp).abs().max(1).values > 1e-5).nonzero().flatten()
+            print("  hidden b", b, "non-finite rows", nf.numel(), nf[:3].tolist(), " wrong rows", werr.numel(), werr[:3].tolist(), werr[-3:].tolist(),
+                  " abs addr of first wrong row mod 4GiB:", ((ws.data_ptr() + L.hidden + (b*T*(U+1) + int(werr[0])) * H * 4) % (1 << 32)) if werr.numel() else None)
+        for b in list(bad[:2]) + [0]:
+            tt, uu = np.meshgrid(np.arange(T), np.arange(U+1), indexing="ij")
+            vb = lpb[b][tt+uu, uu]; dn = den[b][tt+uu, uu]
+            ve = lpe[b][tt+uu, uu][:, :U]; refe = lp[d["targets"][b]][None, :].repeat(T, 0)
+            wb = np.argwhere(~(np.abs(vb - lp[V-1]) < 1e-4)); wd = np.argwhere(~(np.abs(dn - lse) < 1e-4)); we = np.argwhere(~(np.abs(ve - refe) < 1e-4))
+            print("  b", b, "bad lpb", len(wb), wb[:3].tolist(), "bad den", len(wd), wd[:3].tolist(), "bad lpe", len(we), we[:3].tolist(), [float(ve[tuple(x)]) for x in we[:3]])
+            print("     beta[0,0]", be[b][0,0], "alpha[T-1,U]", al[b][T-1+U, U], "nonfinite beta cells", int((~np.isfinite(be[b][tt+uu, uu])).sum()))

@@ -1,0 +1,39 @@
+"""Diagnostic: loss of the fused and the unfused GPU paths vs the fp64 oracle at a mid size
+(long lattice, full H and V), loss only (oracle forward is OpenMP-parallel)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests.helpers import make_inputs
+from oracle import cpu_oracle
+import rnnt_amd
+B, T, U, H, V = 2, 500, 100, 512, 1024
+d = make_inputs(B, T, U, H, V, 5, ragged=True)
+t0 = time.time()
+logits = cpu_oracle.joint_fwd(d["enc"], d["pred"], d["W"], d["bias"], dtype=np.float64)
+costs, _ = cpu_oracle.rnnt_loss(logits, d["targets"], d["logit_lens"], d["target_lens"], want_grad=False)
+print("oracle costs", costs, "in %.1fs" % (time.time() - t0))
+t = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+for name, flags in (("fused (hidden loads)", 0), ("fused (tanh in loop)", 8)):
+    rnnt_amd.engine.lib().rnnt_engine_set_flags(flags)
+    outs = rnnt_amd.engine.joint_loss_fwd_bwd(t["enc"], t["pred"], t["W"], t["bias"], t["targets"], t["logit_lens"], t["target_lens"], V-1, 1.0/B)
+    c = outs[0].cpu().numpy().astype(np.float64)
+    print(name, c, "rel err", np.abs(c - costs) / costs)
+rnnt_amd.engine.lib().rnnt_engine_set_flags(0)
+lg = rnnt_amd.joint_logits(t["enc"], t["pred"], t["W"], t["bias"])
+print("logits max abs err vs oracle:", float(np.abs(lg.cpu().numpy() - logits).max()))
+c2 = rnnt_amd.rnnt_loss(lg, t["targets"], t["logit_lens"], t["target_lens"], reduction="none").cpu().numpy().astype(np.float64)
+print("unfused", c2, "rel err", np.abs(c2 - costs) / costs)
+# ---- stage 0 only: inspect the logits the hidden-load forward wrote
+outs = rnnt_amd.engine.alloc_fused_outputs(t["enc"], t["pred"], t["W"])
+rnnt_amd.engine.joint_loss_fwd_bwd(t["enc"], t["pred"], t["W"], t["bias"], t["targets"], t["logit_lens"], t["target_lens"], V-1, 1.0/B, outs=outs, stage=0)
+torch.cuda.synchronize()
+L = rnnt_amd.engine.layout(B, T, U+1, H, V)
+ws = rnnt_amd.engine._workspaces[("cuda", 0)]
+lg0 = ws[L.logits:L.logits + B*T*(U+1)*V*4].view(torch.float32).view(B, T, U+1, V).cpu().numpy()
+err = np.abs(lg0 - logits)
+for b in range(B):
+    Tb = int(d["logit_lens"][b]); e = err[b, :Tb]
+    print("b", b, "max logits err (t<Tb)", float(e.max()), "cells with err>1e-4:", int((e.max(-1) > 1e-4).sum()), "of", e.shape[0]*e.shape[1])
+    bad = np.argwhere(e.max(-1) > 1e-4)
+    if len(bad):
+        tt, uu = bad[0]; print("   first bad cell", bad[0].tolist(), "last", bad[-1].tolist(), "err row", e[tt, uu, :6], "cols bad", np.nonzero(e[tt,uu] > 1e-4)[0][:10])
