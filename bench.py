@@ -118,11 +118,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
-    device = torch.device("cuda", local_rank)
+    # rehearsal knobs (not used by the driver): BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and
+    # BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 code path can run on a one-GPU box
+    single = os.environ.get("BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if single else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     import rnnt_amd
     from rnnt_amd import engine

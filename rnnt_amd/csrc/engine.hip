@@ -78,7 +78,7 @@ void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
     L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
     L->slab_w = o;   o += align_up((size_t)L->n_split * V * H * 4);
     L->slab_b = o;   o += align_up((size_t)L->n_split * V * 4);
-    L->counters = o; o += 256;
+    L->counters = o; o += 1024;
     L->total = o;
 }
 

@@ -59,19 +59,32 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int n_cb = (H + 127) / 128, n_ub = (U1 + DH_BU - 1) / DH_BU, n_tt = (T + PW_BT - 1) / PW_BT;
-    const long total = (long)a.B * n_tt * n_ub * n_cb;
     const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0
     // V % 8 == 4: in the last chunk lanes 32-63 would start at k >= V; they step back 4
     // (valid addresses) and their G values are zeroed
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
 
-    for (;;) {
+    // Work queues: one counter per XCD.  A tile's n_cb column-block items all read the same
+    // 64 G rows, so they are queued back to back on ONE XCD (tile id mod 8) and the three
+    // re-reads hit that XCD's L2 (one global queue spread them over all XCDs: 105 GB fetched
+    // for 26 GB of G).  HW_REG_XCC_ID only decides which queue a wave serves: any placement is
+    // correct, an uneven one is merely slower.
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const long ntile = (long)a.B * n_tt * n_ub;
+    // serve the own XCD's queue first, then help the others (work stealing): every item is
+    // processed exactly once whatever the placement, even if some XCD hosts no wave at all
+    for (int dq = 0; dq < 8; ++dq) {
+      const unsigned q = (xcc + dq) & 7u;
+      const long q_items = ((ntile - q + 7) / 8) * n_cb;  // tiles q, q+8, ... x column blocks
+      for (;;) {
         long item = 0;
-        if (lane == 0) item = (long)atomicAdd(a.counter, 1u);
+        if (lane == 0) item = (long)atomicAdd(a.counter + q * 16, 1u);
         item = __builtin_amdgcn_readfirstlane((int)item);
-        if (item >= total) break;
+        if (item >= q_items) break;
         const int cb = (int)(item % n_cb);
-        long r_ = item / n_cb;
+        long r_ = (item / n_cb) * 8 + q;  // tile id
         const int ub = (int)(r_ % n_ub); r_ /= n_ub;
         const int tt = (int)(r_ % n_tt);
         const int b = (int)(r_ / n_tt);
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
         const int VK = (V + 7) / 8, last = VK - 1;
         const bool kill = ((V & 7) != 0) && half == 1;
         const int back = kill ? 4 : 0;
-        const int rot = (int)((item * 37) % VK);
+        const int rot = (int)(((item * 8 + q) * 37) % VK);
         auto chunk_of = [&](int c8) { int cc = c8 + rot; cc -= cc >= VK ? VK : 0; cc -= cc >= VK ? VK : 0; return cc; };
         auto load = [&](PwChunk &c, int c8) {
             const int cc = chunk_of(c8);
@@ -198,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
                 }
             }
         }
+      }
     }
 }
 
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ s
 
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 {
-    (void)hipMemsetAsync(a.counter, 0, 16, st);  // work-item counter of the persistent waves
+    (void)hipMemsetAsync(a.counter, 0, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
     hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a);
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,

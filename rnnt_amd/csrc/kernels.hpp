@@ -56,7 +56,7 @@ struct JointBwdArgs {
     float *grad_enc, *grad_pred, *grad_W, *grad_bias;
     int B, T, U1, H, V, blank;
     int n_ublk, n_ttile, n_split;
-    unsigned *counter;  // 16 zeroed bytes: work-item counter of the persistent kernels
+    unsigned *counter;  // 8 x 64 zeroed bytes: per-XCD work-item counters of the persistent kernels
     int n_cu;           // compute units (grid size of the persistent kernels)
     int flags;          // experiment switches (rnnt_engine_set_flags)
 };

@@ -237,6 +237,22 @@ def test_fullsize_config2_closed_form(amd):
     _full(amd, 32, 1000, 200, 512, 1024, seed=2)
 
 
+def test_fullsize_config4_long_utterance_closed_form(amd):
+    """BASELINE config 4 (B=8,T=4000,U=600,H=640,V=1024): ~145 GB workspace, 4600-step lattice
+    sweep, H not a multiple of 128/256/512 tiles: known-answer loss at full size."""
+    amd.engine.release_workspaces()
+    _full(amd, 8, 4000, 600, 640, 1024, seed=4)
+    amd.engine.release_workspaces()
+
+
+def test_fullsize_config5_large_vocab_closed_form(amd):
+    """BASELINE config 5 (B=16,T=800,U=150,H=512,V=16384): 32 forward passes over V, 127 GB of
+    logits, W (32 MiB) larger than an XCD's L2: known-answer loss at full size."""
+    amd.engine.release_workspaces()
+    _full(amd, 16, 800, 150, 512, 16384, seed=5)
+    amd.engine.release_workspaces()
+
+
 def test_fullsize_config2_fused_vs_unfused_subset(amd):
     """Full T,U,H,V of config 2 on 2 utterances: fused engine path vs the unfused GPU path
     (joint GEMM -> rnnt_loss kernels -> torch-op backward): independent backward arithmetic."""
