@@ -179,7 +179,8 @@ def main():
     # stream every kernel was enqueued on: engine._stream()).
     stage_ms = None
     if not args.no_stage_timing:
-        names = ["joint_fwd_gemm", "lattice_sweep", "grad_coef", "dhidden_gemm", "dw_gemm"]
+        names = ["producers_hidden_wpack", "joint_fwd_gemm", "lattice_sweep", "grad_coef_make_g",
+                 "dhidden_gemm", "dhidden_reduce", "dw_gemm", "dw_reduce"]
         reps = max(2, min(args.steps, 5))
         stage_ms = {}
         for s, name in enumerate(names):

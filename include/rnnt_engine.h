@@ -131,8 +131,9 @@ int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,
 /*
  * Run ONE stage of the fused pipeline on an already laid-out workspace (bench/profiling
  * aid: lets bench.py time the dominant kernels with HIP events on the launch stream).
- * stage: 0 pack+joint-forward GEMM, 1 lattice sweep (alpha & beta), 2 gradient
- * coefficients + operand producers (hidden, G in place of logits), 3 dHidden GEMM + dEnc/dPred reduction, 4 dW GEMM + dW/db reduction.
+ * stage: 0 operand producers (hidden = tanh(enc+pred), W repack), 1 joint-forward GEMM kernel,
+ * 2 lattice sweep (alpha & beta), 3 gradient coefficients + G in place of logits, 4 dHidden GEMM
+ * kernel, 5 dEnc/dPred slab reduction, 6 dW GEMM kernel, 7 dW/db slab reduction.
  * Arguments as for rnnt_engine_joint_loss_fwd_bwd.
  */
 int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[3],

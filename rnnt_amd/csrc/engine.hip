@@ -117,7 +117,8 @@ int device_cus()
     return cus;
 }
 
-enum { ST_FWD = 1, ST_LATTICE = 2, ST_COEF = 4, ST_DH = 8, ST_DW = 16, ST_ALL = 31 };
+enum { ST_PROD = 1, ST_FWD = 2, ST_LATTICE = 4, ST_COEF = 8, ST_DH = 16, ST_DH_RED = 32, ST_DW = 64,
+       ST_DW_RED = 128, ST_ALL = 255 };
 
 int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const void *pred,
               const void *W, const void *bias, const int32_t *targets, const int32_t *logit_lens,
@@ -166,9 +167,11 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
     g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags;
 
-    if (stages & ST_FWD) {
+    if (stages & ST_PROD) {
         launch_make_hidden(g, st);  // A operand of the forward GEMM and of both backward GEMMs
         launch_pack_w_fwd((const float *)W, wpack, H, V, st);
+    }
+    if (stages & ST_FWD) {
         JointFwdArgs f;
         f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred;
         f.wpack = wpack; f.hidden = (g_flags & 8) ? nullptr : g.hidden; f.bias = (const float *)bias; f.targets = targets;
@@ -185,7 +188,9 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     {
         if (stages & ST_COEF) launch_make_g(g, st);  // logits -> G in place
         if (stages & ST_DH) launch_dhidden(g, st);
+        if (stages & ST_DH_RED) launch_dhidden_reduce(g, st);
         if (stages & ST_DW) launch_dw(g, st);
+        if (stages & ST_DW_RED) launch_dw_reduce(g, st);
     }
     return launch_status("rnnt_engine fused pipeline");
 }
@@ -326,7 +331,7 @@ int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[
                           void *grad_pred, void *grad_W, void *grad_bias, void *workspace,
                           size_t ws_bytes, void *stream)
 {
-    if (stage < 0 || stage > 4) return fail(RNNT_ERR_INVALID_ARG, "stage %d outside [0,4]", stage);
+    if (stage < 0 || stage > 7) return fail(RNNT_ERR_INVALID_ARG, "stage %d outside [0,7]", stage);
     return run_fused(1 << stage, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens,
                      B, T, U1, H, V, blank, clamp, grad_scale, dtype, costs, grad_enc, grad_pred,
                      grad_W, grad_bias, workspace, ws_bytes, stream);

@@ -253,6 +253,10 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 {
     (void)hipMemsetAsync(a.counter, 0, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
     hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a);
+}
+
+void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)
+{
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,
                        a.slab_enc, a.logit_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);
@@ -396,6 +400,11 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
         const float *gp = a.logits + (k_lo * DW_KC + half) * (long)V + (vok ? vbase : V - 4);
         const float *hp = a.hidden + (k_lo * DW_KC + half) * (long)H + (hok ? hbase : H - 4);
         const long gstep = 2L * V, hstep = 2L * H;
+        // Register ring of DW_RING k-steps: copy the slot out, refill it, then issue the MFMAs.
+        // Measured alternatives: refilling a slot right behind its own MFMAs (the load blocks
+        // until the in-flight MFMAs stop reading it: 50.7 ms), delayed in-place refill (hipcc
+        // still rotates registers and drains with vmcnt(0): 50.7 ms), inline-asm loads (hipcc
+        // copies the pending destinations) — this form: 47.4 ms.
         f32x4 ra[DW_RING], rb[DW_RING];
 #pragma unroll
         for (int s_ = 0; s_ < DW_RING; ++s_) {
@@ -466,6 +475,10 @@ void launch_dw(const JointBwdArgs &a, hipStream_t st)
 {
     const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
     hipLaunchKernelGGL(k_dw, dim3(tiles * a.n_split), dim3(256), 0, st, a);
+}
+
+void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st)
+{
     const long n4w = (long)a.V * a.H / 4;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4w + 255) / 256)), dim3(256), 0, st,
                        a.slab_w, a.grad_W, n4w, a.n_split);

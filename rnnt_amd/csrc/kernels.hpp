@@ -62,5 +62,7 @@ struct JointBwdArgs {
 };
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);
+void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st);
+void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
 void launch_make_g(const JointBwdArgs &a, hipStream_t st);
