@@ -75,8 +75,8 @@ def cpu_baseline(T, U, H, V, budget_s=20.0):
 
     one(1, max(8, T // 50))  # warm-up (thread pools, allocator)
     t_probe = one(1, max(8, T // 10))
-    est_full = t_probe * 10.0
-    B = 2 if est_full * 2 <= budget_s * 1.5 else 1
+    est_full = t_probe * 10.0  # one utterance at full T
+    B = int(max(1, min(8, budget_s // max(est_full, 1e-3))))  # ~10-30 s of CPU work
     dt = one(B, T)
     return {"value": B * T * U / dt, "unit": "cells/s", "cores": threads, "kind": "port",
             "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, 1 run of joint(torch CPU)+loss(C oracle) "
@@ -223,6 +223,16 @@ def main():
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                            "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
+        # HBM traffic of that kernel: not measurable from inside the process; taken from the PMC
+        # profile committed for this config (profiles/r01_traffic.json), else null
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[args.config][dom]
+            if world == 1:
+                out["roofline"]["traffic"] = tr["fetch_raw"] + tr["write"]
+                out["roofline"]["traffic_note"] = ("bytes/launch from rocprofv3 PMC FETCH_SIZE(raw)+WRITE_SIZE, "
+                                                   "profiles/r01_traffic.json; algorithmic HBM bytes %.3g" % tr["algorithmic"])
+        except Exception:  # noqa: BLE001
+            pass
         sweep_bytes = 24.0 * cells1
         out["stages_ms"] = stage_ms
         out["lattice_sweep"] = {"achieved_GBs": sweep_bytes / (stage_ms["lattice_sweep"] * 1e-3) / 1e9,

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
         const int VK = (V + 7) / 8, last = VK - 1;
         const bool kill = ((V & 7) != 0) && half == 1;
         const int back = kill ? 4 : 0;
-        const int rot = (int)(((item * 8 + q) * 37) % VK);
+        const int rot = (int)((((item / n_cb) * 8 + q) * 37) % VK);  // per TILE: its column-block
+        // items then read the same G chunk at about the same time and meet in the XCD's L2
         auto chunk_of = [&](int c8) { int cc = c8 + rot; cc -= cc >= VK ? VK : 0; cc -= cc >= VK ? VK : 0; return cc; };
         auto load = [&](PwChunk &c, int c8) {
             const int cc = chunk_of(c8);
