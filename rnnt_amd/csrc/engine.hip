@@ -165,7 +165,10 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
-    g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags;
+    g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags & ~16;
+    // G inside the dHidden GEMM unless the shape needs the separate pass (or flag 32 forces it)
+    const bool fuse_g = dhidden_gen_ok(H, V) && !(g_flags & 32);
+    if (fuse_g) g.flags |= 16;
 
     if (stages & ST_PROD) {
         launch_make_hidden(g, st);  // A operand of the forward GEMM and of both backward GEMMs
@@ -186,7 +189,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                     B, T, U1, L.D, grad_scale, st);
     {
-        if (stages & ST_COEF) launch_make_g(g, st);  // logits -> G in place
+        if ((stages & ST_COEF) && !fuse_g) launch_make_g(g, st);  // logits -> G in place
         if (stages & ST_DH) launch_dhidden(g, st);
         if (stages & ST_DH_RED) launch_dhidden_reduce(g, st);
         if (stages & ST_DW) launch_dw(g, st);

@@ -216,6 +216,227 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_dhidden_gen — dHidden GEMM that also PRODUCES G (replaces k_make_g + k_dhidden when one
+// workgroup covers all of H, i.e. H <= 512, and V % 32 == 0).
+//
+// k_make_g costs ~10 ms of pure HBM traffic (read 26 GB of logits, write 26 GB of G).  Here the
+// workgroup that owns a 128-cell tile (8 t x 16 u) reads the tile's logits once, turns them into
+// G in registers — exactly one thread per (cell, 4 consecutive k): wave w produces the MFMA
+// A-fragment of M-tile w, in fragment order — hands the fragments to the other waves through a
+// double-buffered 4 KiB LDS exchange (one s_barrier per 8-wide k chunk = per 64 MFMAs per
+// wave) and stores G back over the logits for k_dw.  Each logits element is read and
+// overwritten by the same thread, so the in-place update needs no ordering.
+// 4 waves (one per SIMD) = 2 (M) x 2 (N), wave tile 64 cells x 256 columns, 256 AGPR
+// accumulators; W fragments straight L2 -> VGPR one chunk ahead; logits three chunks ahead.
+// Tiles with t0 >= T_b (ragged batches) only zero their G rows.  grid (n_ublk, ceil(T/8), B).
+#define DG_BT 8
+__global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * 4 * 256 + 2 * 64 * 65];
+    float(*s_red)[64][65] = (float(*)[64][65])(smem + 2 * 4 * 256);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
+    const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
+    const int Tb = a.logit_lens[b];
+    const int t0 = tt * DG_BT, u0 = ub * DH_BU;
+    const int VK = V / 8;
+
+    // ---- this lane's producer row (M-tile `wave`, row i): one lattice cell or none
+    const int prow = wave * 32 + i;
+    const int pt = t0 + (prow >> 4), pu = u0 + (prow & 15);
+    const bool pexists = pt < T && pu < U1;
+    const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : (long)a.B * T * U1;  // else zero row
+    float *lptr = (float *)a.logits + pcell * V + 4 * half;
+
+    if (t0 >= Tb) {  // workgroup-uniform: nothing to multiply, but k_dw must find zeros here
+        if (pexists) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;
+        }
+        return;
+    }
+
+    CellCoef cf = a.coef[pexists ? pcell : 0];
+    const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
+    const int ncol0 = wn * 256;
+    const int colg[2] = {ncol0 + 4 * i, ncol0 + 128 + 4 * i};
+    const bool colok[2] = {colg[0] < H, colg[1] < H};
+    // columns beyond H read column 0: they feed accumulators that are never stored
+    const float *wptr[2] = {a.W + (long)(4 * half) * H + (colok[0] ? colg[0] : 0),
+                            a.W + (long)(4 * half) * H + (colok[1] ? colg[1] : 0)};
+
+    f32x16 acc[2][8];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+
+    // G of chunk c8 for this lane's (row, 4 k): exp2(x*log2e + c1) - fixups.  Rows outside the
+    // lattice read the zero padding row with c1 = -inf (exp2 -> 0): no per-element select.  The
+    // two fixups touch one element of one chunk per row, so they sit behind wave-uniform tests.
+    if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
+    const float *xsrc = live ? lptr : a.logits + (long)a.B * T * U1 * V + 4 * half;
+    const long xstep = live ? 8 : 0;  // the zero row is only 1 row long: re-read its start
+    auto gen = [&](const f32x4 &x, int c8) {
+        f32x4 g;
+        const int vb = 8 * c8 + 4 * half;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) g[s_] = __builtin_amdgcn_exp2f(fmaf(x[s_], RNNT_LOG2E, cf.c1));
+        const unsigned dy = (unsigned)(cf.y - vb);
+        if (__any(dy < 4u)) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                if (dy == (unsigned)s_) g[s_] -= cf.se;
+        }
+        if (8 * c8 <= a.blank && a.blank < 8 * c8 + 8) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                if (vb + s_ == a.blank) g[s_] -= cf.sb;
+        }
+        return g;
+    };
+    auto wload = [&](f32x4 (&w)[4][2], int c8) {
+        const int cc = c8 < VK ? c8 : VK - 1;  // the last refill re-reads the final chunk (unused)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) w[s_][g] = *(const f32x4 *)(wptr[g] + (long)(8 * cc + s_) * H);
+    };
+    auto xload = [&](int c8) { return *(const f32x4 *)(xsrc + xstep * (c8 < VK ? c8 : VK - 1)); };
+
+    f32x4 xr[4];           // raw logits of chunks c+1 .. c+4 (ring, slot = chunk & 3)
+    f32x4 wf[2][4][2];     // W fragments of chunks c, c+1 (slot = chunk & 1)
+    xr[0] = xload(0); xr[1] = xload(1); xr[2] = xload(2); xr[3] = xload(3);
+    wload(wf[0], 0);
+    wload(wf[1], 1);
+    {
+        const f32x4 g0 = gen(xr[0], 0);
+        *(f32x4 *)(smem + wave * 256 + 4 * lane) = g0;
+        if (pexists) *(f32x4 *)lptr = g0;
+        xr[0] = xload(4);
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < VK; c0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c8 = c0 + j;  // VK % 4 == 0
+            const float *gb = smem + (j & 1) * 1024;
+            const f32x4 a0 = *(const f32x4 *)(gb + (2 * wm) * 256 + 4 * lane);
+            const f32x4 a1 = *(const f32x4 *)(gb + (2 * wm + 1) * 256 + 4 * lane);
+            // produce chunk c8+1 (its logits were requested three chunks ago)
+            if (c8 + 1 < VK) {
+                const f32x4 gn = gen(xr[(j + 1) & 3], c8 + 1);
+                *(f32x4 *)(smem + ((j + 1) & 1) * 1024 + wave * 256 + 4 * lane) = gn;
+                if (pexists) *(f32x4 *)(lptr + 8 * (c8 + 1)) = gn;
+            }
+            xr[(j + 1) & 3] = xload(c8 + 5);
+            f32x4 cur[4][2];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) cur[s_][g] = wf[j & 1][s_][g];
+            wload(wf[j & 1], c8 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float gv = mt == 0 ? a0[s_] : a1[s_];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                gv, cur[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            // publish chunk c8+1's fragments / free chunk c8's buffer.  Raw barrier: a
+            // __syncthreads() would add s_waitcnt vmcnt(0) and drain the logits / W prefetch.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
+    float psum[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
+    const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            const int t = t0 + wm * 4 + mt * 2 + rh;
+            const bool tok = t < Tb;
+            float esum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r7 = 0; r7 < 8; ++r7) {
+                const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+                const bool rok = tok && u < U1;
+                const float *hrow = a.hidden + (((long)b * T + (rok ? t : 0)) * U1 + (rok ? u : 0)) * H;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const bool ok = rok && colok[g];
+                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) h4 = *(const f32x4 *)(hrow + colg[g]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d =
+                            ok ? acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
+                        esum[g * 4 + q] += d;
+                        psum[r7][g * 4 + q] += d;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
+            if (half == 0 && tok) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
+                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
+                    }
+            }
+        }
+    if (wm == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_red[wn][lane][k * 8 + q] = psum[k][q];
+    }
+    __syncthreads();
+    if (wm == 0) {
+#pragma unroll
+        for (int r7 = 0; r7 < 8; ++r7) {
+            const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+            if (u < U1) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            o[q] = psum[r7][g * 4 + q] + s_red[wn][lane][r7 * 8 + g * 4 + q];
+                        *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + colg[g]) = o;
+                    }
+            }
+        }
+    }
+}
+
+bool dhidden_gen_ok(int H, int V) { return H <= 512 && (V % 32) == 0; }
+
 // out[b,t,:] = sum_ub slab_enc[ub][b,t,:]  (0 for t >= T_b)
 __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ slab,
                                                     const int32_t *__restrict__ logit_lens,
@@ -237,14 +458,15 @@ __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ sl
 // out[b,u,:] = sum_{tt < ceil(T_b/8)} slab_pred[tt][b,u,:]
 __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ slab,
                                                      const int32_t *__restrict__ logit_lens,
-                                                     float *__restrict__ out, int B, int U1, int H)
+                                                     float *__restrict__ out, int B, int U1, int H,
+                                                     int bt)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int H4 = H / 4;
     const long n = (long)B * U1 * H4;
     if (idx >= n) return;
     const int b = (int)(idx / ((long)U1 * H4));
-    const int ntt = (logit_lens[b] + PW_BT - 1) / PW_BT;
+    const int ntt = (logit_lens[b] + bt - 1) / bt;  // slabs written: t tiles of height bt
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < ntt; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
     ((f32x4 *)out)[idx] = s;
@@ -252,6 +474,14 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ s
 
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 {
+    if (a.flags & 16) {  // fused G producer (engine decides: dhidden_gen_ok)
+        // zero the padding rows k_dw may touch (k_make_g used to)
+        const long cells = (long)a.B * a.T * a.U1;
+        (void)hipMemsetAsync((float *)a.logits + cells * a.V, 0, (size_t)(a.rows_pad + 16 - cells) * a.V * 4, st);
+        dim3 grid(a.n_ublk, (a.T + DG_BT - 1) / DG_BT, a.B);
+        hipLaunchKernelGGL(k_dhidden_gen, grid, dim3(256), 0, st, a);
+        return;
+    }
     (void)hipMemsetAsync(a.counter, 0, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
     hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a);
 }
@@ -263,7 +493,8 @@ void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)
                        a.slab_enc, a.logit_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);
     const long n4p = (long)a.B * a.U1 * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_pred, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st,
-                       a.slab_pred, a.logit_lens, a.grad_pred, a.B, a.U1, a.H);
+                       a.slab_pred, a.logit_lens, a.grad_pred, a.B, a.U1, a.H,
+                       (a.flags & 16) ? DG_BT : PW_BT);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ struct JointBwdArgs {
     int n_ublk, n_ttile, n_split;
     unsigned *counter;  // 8 x 64 zeroed bytes: per-XCD work-item counters of the persistent kernels
     int n_cu;           // compute units (grid size of the persistent kernels)
-    int flags;          // experiment switches (rnnt_engine_set_flags)
+    int flags;          // bit 4 (16): G is produced by k_dhidden_gen; others: experiment switches
 };
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);
@@ -66,3 +66,4 @@ void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
 void launch_make_g(const JointBwdArgs &a, hipStream_t st);
+bool dhidden_gen_ok(int H, int V);  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
