@@ -65,6 +65,13 @@ def test_fused_joint_loss_vs_oracle(amd, shape):
     _compare(_run_fused(amd, d), oracle_fused(d))
 
 
+def test_fused_config1_plumbing_shape_vs_oracle(amd):
+    """BASELINE.json configs[0]'s shape (B=2, T~200, U~50, H=1024, V=1024): H > 512 takes the
+    persistent dHidden kernel + k_make_g route."""
+    d = make_inputs(2, 208, 50, 1024, 1024, seed=208)
+    _compare(_run_fused(amd, d), oracle_fused(d))
+
+
 def test_fused_noncontiguous_encoder_view(amd):
     """The reference hands the joint a permuted (B,C,T)->(B,T,C) view (rnnt/model.py:27-28)."""
     d = make_inputs(2, 21, 6, 48, 64, seed=5)
