@@ -83,21 +83,24 @@ def cpu_baseline(T, U, H, V, budget_s=20.0):
                       f"fwd+bwd in {dt:.2f}s", "os_cpu_count": os.cpu_count()}
 
 
-def parity_twin(H, V, device):
-    """Loss / gradient error of a down-scaled twin of the workload against the fp64 oracle."""
+def parity_twin(H, V, device, dtype="fp32"):
+    """Loss / gradient error of a down-scaled twin of the workload against the fp64 oracle
+    (bf16 route: the oracle with the same bf16 rounding points, tests/helpers.py)."""
     import rnnt_amd
-    from tests.helpers import make_inputs, oracle_fused
+    from tests.helpers import make_inputs, oracle_fused, oracle_fused_bf16
     d = make_inputs(2, 48, 12, H, V, seed=7)
     t = {k: torch.from_numpy(v).to(device) for k, v in d.items()}
     outs = rnnt_amd.engine.joint_loss_fwd_bwd(t["enc"], t["pred"], t["W"], t["bias"], t["targets"],
-                                              t["logit_lens"], t["target_lens"], V - 1, 0.5)
+                                              t["logit_lens"], t["target_lens"], V - 1, 0.5,
+                                              dtype=dtype)
     torch.cuda.synchronize()
-    ref = oracle_fused(d)
+    ref = oracle_fused_bf16(d) if dtype == "bf16" else oracle_fused(d)
     loss = float(outs[0].double().mean())
     gerr = max(float(np.abs(o.cpu().numpy() - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30))
                for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")))
     return {"loss_rel_err": abs(loss - ref["loss"]) / abs(ref["loss"]), "grad_rel_err": gerr,
-            "twin": "B=2,T=48,U=12 ragged, same H,V, vs fp64 oracle"}
+            "twin": "B=2,T=48,U=12 ragged, same H,V, vs fp64 oracle" +
+                    (" with bf16 rounding points" if dtype == "bf16" else "")}
 
 
 def main():
@@ -106,6 +109,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE config 3's arithmetic (bf16 GEMM operands, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
@@ -153,7 +158,8 @@ def main():
     outs = (costs, ge, gp, gW, gb)
 
     def step():
-        engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs)
+        engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs,
+                                  dtype=args.dtype)
         fg.set_loss(costs, scale)
         fg.all_reduce()  # N>1: one RCCL all-reduce over xGMI of dW, db and the loss
 
@@ -184,11 +190,13 @@ def main():
         reps = max(2, min(args.steps, 5))
         stage_ms = {}
         for s, name in enumerate(names):
-            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s)
+            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s,
+                                      dtype=args.dtype)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s)
+                engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s,
+                                          dtype=args.dtype)
             e1.record(); e1.synchronize()
             stage_ms[name] = e0.elapsed_time(e1) / reps
 
@@ -206,8 +214,8 @@ def main():
         "unit": "cells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} fp32 joint+loss fwd+bwd",
+        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} {args.dtype} joint+loss fwd+bwd",
                    "global_batch": B, "per_gpu_batch": Bl, "parallelism": f"dp{world}",
                    "cells_BTU1": B * T * (U + 1)},
         "loss": loss,
@@ -223,10 +231,20 @@ def main():
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                            "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
+        if args.dtype == "bf16":
+            # 16x the matrix rate: every kernel of this route is HBM-bound.  Algorithmic bytes per
+            # cell (rnnt_amd/csrc/bf16.hip header): fwd 2H+4V, dHidden 4V+2V+2H, dW 2V+2H
+            per_cell = {"joint_fwd_gemm": 2 * H + 4 * V, "dhidden_gemm": 6 * V + 2 * H, "dw_gemm": 2 * V + 2 * H}
+            gbs = per_cell[dom] * cells1 / (gemms[dom] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                               "bytes_per_launch": per_cell[dom] * cells1, "ms_per_launch": gemms[dom],
+                               "mfma_tflops": ach}
         # HBM traffic of that kernel: not measurable from inside the process; taken from the PMC
         # profile committed for this config (profiles/r01_traffic.json), else null
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[args.config][dom]
+            key = args.config if args.dtype == "fp32" else args.config + "_bf16"
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[key][dom]
             if world == 1:
                 out["roofline"]["traffic"] = tr["fetch_raw"] + tr["write"]
                 out["roofline"]["traffic_note"] = ("bytes/launch from rocprofv3 PMC FETCH_SIZE(raw)+WRITE_SIZE, "
@@ -241,7 +259,7 @@ def main():
     if world == 1:
         if not args.no_parity:
             try:
-                out["parity"] = parity_twin(H, V, device)
+                out["parity"] = parity_twin(H, V, device, args.dtype)
             except Exception as e:  # noqa: BLE001
                 out["parity"] = {"error": repr(e)}
         if not args.no_cpu_baseline:

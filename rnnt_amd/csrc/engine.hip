@@ -33,7 +33,12 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
 {
-    if (dtype != RNNT_DTYPE_F32) return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (fp32 only)", dtype);
+    if (dtype != RNNT_DTYPE_F32 && dtype != RNNT_DTYPE_BF16)
+        return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (RNNT_DTYPE_F32 / RNNT_DTYPE_BF16)", dtype);
+    if (dtype == RNNT_DTYPE_BF16 && !need_h)
+        return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 only applies to the fused joint+loss entry");
+    if (dtype == RNNT_DTYPE_BF16 && (H <= 0 || H % 128 != 0 || H > 512 || V <= 0 || V % 128 != 0))
+        return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 needs H %% 128 == 0, H <= 512, V %% 128 == 0 (H=%d V=%d)", H, V);
     if (B <= 0 || T <= 0 || U1 <= 0 || V <= 0 || (need_h && H <= 0))
         return fail(RNNT_ERR_INVALID_ARG, "non-positive dimension B=%d T=%d U1=%d H=%d V=%d", B, T, U1, H, V);
     if (V % 4 != 0) return fail(RNNT_ERR_UNSUPPORTED, "V=%d must be a multiple of 4 (pad on the host side)", V);
@@ -52,7 +57,9 @@ int dw_splits(int B, int T, int H, int V)
     return (int)s;
 }
 
-void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
+long bf16_rows_alloc(size_t rows_pad) { return (long)((rows_pad + 64 + 127) / 128 * 128); }
+
+void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout *L)
 {
     const size_t D = (size_t)T + U1 - 1;
     const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
@@ -64,15 +71,24 @@ void layout(int B, int T, int U1, int H, int V, rnnt_engine_ws_layout *L)
     L->n_ttile = (T + 3) / 4;
     L->n_split = dw_splits(B, T, H, V);
     size_t o = 0;
-    L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
-    L->hidden = o;   o += align_up((rows_pad + 16) * H * 4);
+    if (dtype == RNNT_DTYPE_BF16) {
+        // row tiles of 128 for the forward GEMM; the dW ring over-reads 64 (zero) rows
+        const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
+        L->logits = o;   o += align_up(ra * V * 4);
+        L->hidden = o;   o += align_up(ra * H * 2);
+    } else {
+        L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
+        L->hidden = o;   o += align_up((rows_pad + 16) * H * 4);
+    }
     L->denom_s = o;  o += align_up(skew * 4);
     L->lpb_s = o;    o += align_up(skew * 4);
     L->lpe_s = o;    o += align_up(skew * 4);
     L->alpha_s = o;  o += align_up(skew * 8);
     L->beta_s = o;   o += align_up(skew * 8);
     L->coef = o;     o += align_up(cells * 16);
-    L->wpack = o;    o += align_up(wpack_floats(H, V) * 4);
+    L->wpack = o;
+    if (dtype == RNNT_DTYPE_BF16) o += align_up(bf16_wpack_fwd_bytes(H, V)) + align_up(bf16_wpack_dh_bytes(V));
+    else o += align_up(wpack_floats(H, V) * 4);
     L->enc_copy = o; o += align_up((size_t)B * T * H * 4);
     L->slab_enc = o; o += align_up((size_t)L->n_ublk * B * T * H * 4);
     L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
@@ -139,7 +155,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         ((uintptr_t)workspace & 255))
         return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
     rnnt_engine_ws_layout L;
-    layout(B, T, U1, H, V, &L);
+    layout(B, T, U1, H, V, dtype, &L);
     if (ws_bytes < L.total)
         return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, L.total);
 
@@ -166,6 +182,35 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
     g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags & ~16;
+    if (dtype == RNNT_DTYPE_BF16) {
+        Bf16Args h;
+        h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;
+        h.W = (const float *)W; h.bias = (const float *)bias;
+        h.hidden = (unsigned short *)(ws + L.hidden);
+        h.wpack_fwd = ws + L.wpack; h.wpack_dh = ws + L.wpack + align_up(bf16_wpack_fwd_bytes(H, V));
+        h.logits = logits; h.coef = coef; h.logit_lens = logit_lens;
+        h.slab_enc = g.slab_enc; h.slab_pred = g.slab_pred; h.slab_w = g.slab_w; h.slab_b = g.slab_b;
+        h.rows_pad = (long)L.rows_pad; h.rows_alloc = bf16_rows_alloc(L.rows_pad);
+        h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
+        h.n_ublk = L.n_ublk; h.n_split = L.n_split;
+        g.flags |= 16;  // reductions: dPred slabs are 8 t-rows high, as in k_dhidden_gen
+        if (stages & ST_PROD) launch_bf16_producers(h, st);
+        if (stages & ST_FWD) {
+            launch_joint_fwd_bf16(h, st);
+            launch_logsoftmax_gather(logits, targets, logit_lens, target_lens, denom_s, lpb_s, lpe_s,
+                                     B, T, U1, V, L.D, blank, st);
+        }
+        if (stages & ST_LATTICE)
+            launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D, st);
+        if (stages & ST_COEF)
+            launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
+                        B, T, U1, L.D, grad_scale, st);
+        if (stages & ST_DH) launch_dhidden_bf16(h, st);
+        if (stages & ST_DH_RED) launch_dhidden_reduce(g, st);
+        if (stages & ST_DW) launch_dw_bf16(h, st);
+        if (stages & ST_DW_RED) launch_dw_reduce(g, st);
+        return launch_status("rnnt_engine fused pipeline (bf16)");
+    }
     // G inside the dHidden GEMM unless the shape needs the separate pass (or flag 32 forces it)
     const bool fuse_g = dhidden_gen_ok(H, V) && !(g_flags & 32);
     if (fuse_g) g.flags |= 16;
@@ -217,7 +262,7 @@ int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,
 {
     if (!out) return fail(RNNT_ERR_INVALID_ARG, "null layout pointer");
     if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
-    layout(B, T, U1, H, V, out);
+    layout(B, T, U1, H, V, dtype, out);
     return RNNT_OK;
 }
 

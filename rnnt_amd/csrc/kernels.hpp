@@ -67,3 +67,27 @@ void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
 void launch_make_g(const JointBwdArgs &a, hipStream_t st);
 bool dhidden_gen_ok(int H, int V);  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
+
+// ---- bf16.hip (RNNT_DTYPE_BF16 route: bf16 GEMM operands, fp32 accumulate / logits / loss)
+struct Bf16Args {
+    const float *enc; long enc_sb, enc_st;
+    const float *pred;
+    const float *W;      // [V,H] fp32 (re-packed to bf16 fragment order every call)
+    const float *bias;
+    unsigned short *hidden;  // bf16 [rows_alloc,H] tanh(enc+pred)
+    void *wpack_fwd, *wpack_dh;
+    float *logits;       // fp32 [rows_alloc,V]; G (bf16) overwrites the first half of each row
+    const CellCoef *coef;
+    const int32_t *logit_lens;
+    float *slab_enc, *slab_pred, *slab_w, *slab_b;
+    long rows_alloc;     // multiple of 128, >= rows_pad + 64; rows >= B*T*U1 are zero
+    long rows_pad;       // K extent of the dW GEMM (multiple of 16)
+    int B, T, U1, H, V, blank;
+    int n_ublk, n_split;
+};
+size_t bf16_wpack_fwd_bytes(int H, int V);
+size_t bf16_wpack_dh_bytes(int V);
+void launch_bf16_producers(const Bf16Args &a, hipStream_t st);
+void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st);
+void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st);
+void launch_dw_bf16(const Bf16Args &a, hipStream_t st);

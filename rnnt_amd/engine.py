@@ -16,6 +16,18 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "librnnt_engine.so")
 
 DTYPE_F32 = 0
+DTYPE_BF16 = 1  # bf16 GEMM operands, fp32 accumulate / logits / loss; fp32 tensors at the boundary
+_DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, DTYPE_F32: DTYPE_F32,
+           "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, DTYPE_BF16: DTYPE_BF16}
+
+
+def dtype_code(dtype):
+    if isinstance(dtype, torch.dtype):
+        dtype = {torch.float32: "fp32", torch.bfloat16: "bf16"}.get(dtype, dtype)
+    try:
+        return _DTYPES[dtype]
+    except (KeyError, TypeError):
+        raise ValueError(f"rnnt_amd: unsupported compute dtype {dtype!r} (fp32 or bf16)") from None
 _lock = threading.Lock()
 _lib = None
 _workspaces = {}
@@ -117,15 +129,15 @@ def release_workspaces():
     _workspaces.clear()
 
 
-def layout(B, T, U1, H, V):
+def layout(B, T, U1, H, V, dtype="fp32"):
     L = WsLayout()
-    _check(lib().rnnt_engine_workspace_layout(B, T, U1, H, V, DTYPE_F32, ctypes.byref(L)))
+    _check(lib().rnnt_engine_workspace_layout(B, T, U1, H, V, dtype_code(dtype), ctypes.byref(L)))
     return L
 
 
-def workspace_bytes(B, T, U1, H, V):
+def workspace_bytes(B, T, U1, H, V, dtype="fp32"):
     n = ctypes.c_size_t(0)
-    _check(lib().rnnt_engine_workspace_bytes(B, T, U1, H, V, DTYPE_F32, ctypes.byref(n)))
+    _check(lib().rnnt_engine_workspace_bytes(B, T, U1, H, V, dtype_code(dtype), ctypes.byref(n)))
     return n.value
 
 
@@ -168,14 +180,15 @@ def loss_fwd_bwd(logits, targets, logit_lens, target_lens, blank, clamp=-1.0, wa
     return costs, grad
 
 
-def _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale, outs, ws):
+def _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale, outs, ws,
+                dtype=DTYPE_F32):
     B, T, H = enc.shape
     U1 = pred.shape[1]
     V = W.shape[0]
     costs, ge, gp, gW, gb = outs
     return (_p(enc), _strides3(enc), _p(pred), _p(W), _p(bias), _p(targets), _p(logit_lens),
             _p(target_lens), B, T, U1, H, V, int(blank), ctypes.c_float(-1.0),
-            ctypes.c_float(grad_scale), DTYPE_F32, _p(costs), _p(ge), _p(gp), _p(gW), _p(gb),
+            ctypes.c_float(grad_scale), dtype, _p(costs), _p(ge), _p(gp), _p(gW), _p(gb),
             _p(ws), ctypes.c_size_t(ws.numel()), _stream(enc.device))
 
 
@@ -190,10 +203,11 @@ def alloc_fused_outputs(enc, pred, W):
 
 
 def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
-                       outs=None, stage=None):
+                       outs=None, stage=None, dtype="fp32"):
     """Fused joint + transducer loss forward AND backward (one C-ABI call).
     Returns (costs[B], grad_enc, grad_pred, grad_W, grad_bias); gradients are those of
-    grad_scale * sum_b costs[b].  `stage` (0..4) runs a single pipeline stage (bench aid)."""
+    grad_scale * sum_b costs[b].  `stage` (0..7) runs a single pipeline stage (bench aid).
+    `dtype` "bf16": the three GEMMs take bf16-rounded operands (tensors stay fp32)."""
     dev = _require_cuda(enc, pred, W, bias, targets, logit_lens, target_lens)
     B, T, H = enc.shape
     U1 = pred.shape[1]
@@ -201,9 +215,10 @@ def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, bla
     targets = _nonempty(targets)
     if outs is None:
         outs = alloc_fused_outputs(enc, pred, W)
-    ws = workspace(dev, workspace_bytes(B, T, U1, H, V))
+    code = dtype_code(dtype)
+    ws = workspace(dev, workspace_bytes(B, T, U1, H, V, code))
     args = _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
-                       outs, ws)
+                       outs, ws, code)
     if stage is None:
         _check(lib().rnnt_engine_joint_loss_fwd_bwd(*args))
     else:

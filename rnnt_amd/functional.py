@@ -140,10 +140,11 @@ def joint_logits(enc, pred, W, bias):
 
 class _JointRNNTLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, pred, W, bias, targets, logit_lengths, target_lengths, blank, scale):
+    def forward(ctx, enc, pred, W, bias, targets, logit_lengths, target_lengths, blank, scale,
+                dtype="fp32"):
         costs, ge, gp, gW, gb = engine.joint_loss_fwd_bwd(
             enc, pred.contiguous(), W.contiguous(), bias.contiguous(), targets, logit_lengths,
-            target_lengths, blank, scale)
+            target_lengths, blank, scale, dtype=dtype)
         ctx.save_for_backward(ge, gp, gW, gb)
         ctx.scale = scale
         ctx.mark_non_differentiable(costs)
@@ -153,17 +154,20 @@ class _JointRNNTLoss(torch.autograd.Function):
     def backward(ctx, grad_loss, _grad_costs):
         ge, gp, gW, gb = ctx.saved_tensors
         return (ge * grad_loss, gp * grad_loss, gW * grad_loss, gb * grad_loss,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, blank=-1,
-                    reduction="mean", check_lengths=True, return_costs=False, grad_scale=None):
+                    reduction="mean", check_lengths=True, return_costs=False, grad_scale=None,
+                    dtype="fp32"):
     """Fused replacement of
         logits = joint(enc, pred)                      # reference rnnt/model.py:32
         loss = torchaudio.functional.rnnt_loss(logits, targets, ..., blank, clamp=-1, reduction)
     (rnnt/model.py:35-41) including everything loss.backward() (rnnt/train.py:134) sends to
     enc, pred, W and bias.  enc [B,T,H] (any strides), pred [B,U+1,H], W [V,H], bias [V].
-    `grad_scale` overrides the reduction factor (1/B_global when the batch is sharded)."""
+    `grad_scale` overrides the reduction factor (1/B_global when the batch is sharded).
+    `dtype="bf16"` (BASELINE config 3): tensors stay fp32, the three GEMMs run on bf16-rounded
+    operands with fp32 accumulation; needs H % 128 == 0, H <= 512, V % 128 == 0."""
     if reduction not in ("mean", "sum"):
         if reduction == "none":
             raise NotImplementedError(
@@ -181,8 +185,12 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
         raise RuntimeError("enc / pred / W shape mismatch")
     blank = _check_loss_args(T, U1, V, B, targets, logit_lengths, target_lengths, blank, reduction,
                              check_lengths)
-    enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
+    code = engine.dtype_code(dtype)
+    if code == engine.DTYPE_BF16:  # no host-side padding on this route: the C side validates
+        enc_p, pred_p, W_p, bias_p = enc, pred, W, bias
+    else:
+        enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
     scale = float(grad_scale) if grad_scale is not None else (1.0 / B if reduction == "mean" else 1.0)
     loss, costs = _JointRNNTLoss.apply(enc_p, pred_p, W_p, bias_p, targets, logit_lengths,
-                                       target_lengths, blank, scale)
+                                       target_lengths, blank, scale, code)
     return (loss, costs) if return_costs else loss

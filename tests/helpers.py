@@ -62,3 +62,35 @@ def lgamma_paths_cost(T, U, lp_blank, lp_emit_sum):
     from math import lgamma
     log_paths = lgamma(T + U) - lgamma(U + 1) - lgamma(T)
     return -(log_paths + T * lp_blank + lp_emit_sum)
+
+
+# ---- bf16 route (BASELINE config 3): the oracle with the SAME rounding points as the engine
+# (include/rnnt_engine.h RNNT_DTYPE_BF16): tanh(enc+pred), W and the logits gradient are rounded
+# to bf16 (nearest-even) before each matrix product; everything else is float64.
+BF16_LOSS_RTOL = 1e-3       # vs the rounding-point oracle (fp32 accumulation, rare 1-ulp flips)
+BF16_GRAD_RTOL = 1e-2
+BF16_LOSS_RTOL_EXACT = 2e-2  # vs the unrounded float64 oracle: what bf16 operands cost
+BF16_GRAD_RTOL_EXACT = 6e-2
+
+
+def bf16_round(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+
+def oracle_fused_bf16(d):
+    enc, pred, W, bias = d["enc"], d["pred"], d["W"], d["bias"]
+    B, T, H = enc.shape
+    U1, V = pred.shape[1], W.shape[0]
+    hidden = bf16_round(np.tanh(enc[:, :, None, :].astype(np.float64) +
+                                pred[:, None, :, :].astype(np.float64)).astype(np.float32)).astype(np.float64)
+    Wb = bf16_round(W).astype(np.float64)
+    logits = (hidden.reshape(-1, H) @ Wb.T + bias.astype(np.float64)).astype(np.float32)
+    logits = logits.reshape(B, T, U1, V)
+    costs, G = cpu_oracle.rnnt_loss(logits, d["targets"], d["logit_lens"], d["target_lens"], blank=-1,
+                                    dtype=np.float64)
+    Gb = bf16_round((G / B).astype(np.float32)).astype(np.float64).reshape(-1, V)
+    dpre = (Gb @ Wb).reshape(B, T, U1, H) * (1.0 - hidden * hidden)
+    return dict(loss=costs.mean(), costs=costs, grad_enc=dpre.sum(2), grad_pred=dpre.sum(1),
+                grad_W=Gb.T @ hidden.reshape(-1, H), grad_bias=Gb.sum(0))

@@ -7,8 +7,9 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import (assert_close_grad, assert_close_loss, lgamma_paths_cost, make_inputs,
-                           oracle_fused)
+from tests.helpers import (BF16_GRAD_RTOL, BF16_GRAD_RTOL_EXACT, BF16_LOSS_RTOL,
+                           BF16_LOSS_RTOL_EXACT, assert_close_grad, assert_close_loss,
+                           lgamma_paths_cost, make_inputs, oracle_fused, oracle_fused_bf16)
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +26,7 @@ def _dev(d):
     return {k: torch.from_numpy(v).cuda() for k, v in d.items()}
 
 
-def _run_fused(amd, d, enc_override=None):
+def _run_fused(amd, d, enc_override=None, dtype="fp32"):
     g = _dev(d)
     enc = enc_override if enc_override is not None else g["enc"]
     enc = enc.detach().requires_grad_(True)
@@ -34,7 +35,7 @@ def _run_fused(amd, d, enc_override=None):
     bias = g["bias"].requires_grad_(True)
     loss, costs = amd.joint_rnnt_loss(enc, pred, W, bias, g["targets"], g["logit_lens"],
                                       g["target_lens"], blank=-1, reduction="mean",
-                                      return_costs=True)
+                                      return_costs=True, dtype=dtype)
     loss.backward()
     torch.cuda.synchronize()
     return dict(loss=loss.item(), costs=costs.cpu().numpy(), grad_enc=enc.grad.cpu().numpy(),
@@ -290,3 +291,33 @@ def test_fullsize_config2_fused_vs_unfused_subset(amd):
     assert_close_grad("grad_W", r["grad_W"], W.grad.cpu().numpy(), rtol=5e-4)
     assert_close_grad("grad_bias", r["grad_bias"], bias.grad.cpu().numpy(), rtol=5e-4)
     amd.engine.release_workspaces()
+
+
+# ---- bf16 route (BASELINE config 3).  (B, T, U, H, V): ragged, several u-blocks / t-tiles /
+# forward passes / dW tiles and splits, dead tiles (t0 >= T_b), H < 512
+BF16_SHAPES = [(1, 1, 0, 128, 128), (2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024),
+               (4, 30, 12, 384, 256), (1, 70, 40, 128, 2048)]
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_bf16_fused_vs_rounding_point_oracle(amd, shape):
+    """bf16 GEMM operands, fp32 accumulate: against the float64 oracle that rounds tanh(enc+pred),
+    W and the logits gradient to bf16 at the same points, and (looser) against the unrounded one."""
+    B, T, U, H, V = shape
+    d = make_inputs(B, T, U, H, V, seed=sum(shape) + 1)
+    r = _run_fused(amd, d, dtype="bf16")
+    ref = oracle_fused_bf16(d)
+    assert_close_loss("loss", r["loss"], ref["loss"], rtol=BF16_LOSS_RTOL)
+    assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL)
+    exact = oracle_fused(d)
+    assert_close_loss("loss vs unrounded", r["loss"], exact["loss"], rtol=BF16_LOSS_RTOL_EXACT)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k + " vs unrounded", r[k], exact[k], rtol=BF16_GRAD_RTOL_EXACT)
+
+
+def test_bf16_rejects_unsupported_dims(amd):
+    d = make_inputs(2, 5, 2, 64, 128, seed=3)
+    with pytest.raises(RuntimeError, match="RNNT_DTYPE_BF16"):
+        _run_fused(amd, d, dtype="bf16")
