@@ -58,23 +58,27 @@ __device__ __forceinline__ void lds_barrier()
 // hidden[c,:] = bf16(tanh(enc[b,t,:] + pred[b,u,:])), zero rows for c >= cells (row padding)
 __global__ __launch_bounds__(256) void k_make_hidden_bf16(const float *__restrict__ enc, long sb,
                                                           long st_, const float *__restrict__ pred,
-                                                          u32x2 *__restrict__ hid, int B, int T,
+                                                          u32x4 *__restrict__ hid, int B, int T,
                                                           int U1, int H, long rows)
 {
-    const int H4 = H / 4;
+    const int H8 = H / 8;  // 8 columns (16 B of bf16) per thread
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * H4) return;
-    const long c = idx / H4;
-    const int h = (int)(idx - c * H4) * 4;
-    u32x2 o = {0u, 0u};
+    if (idx >= rows * H8) return;
+    const long c = idx / H8;
+    const int h = (int)(idx - c * H8) * 8;
+    u32x4 o = {0u, 0u, 0u, 0u};
     if (c < (long)B * T * U1) {
         const int u = (int)(c % U1);
         const long bt = c / U1;
         const int t = (int)(bt % T), b = (int)(bt / T);
-        const f32x4 e = *(const f32x4 *)(enc + (long)b * sb + (long)t * st_ + h);
-        const f32x4 p = *(const f32x4 *)(pred + ((long)b * U1 + u) * H + h);
-        o[0] = pack_bf16(fast_tanh(e[0] + p[0]), fast_tanh(e[1] + p[1]));
-        o[1] = pack_bf16(fast_tanh(e[2] + p[2]), fast_tanh(e[3] + p[3]));
+        const float *ep = enc + (long)b * sb + (long)t * st_ + h;
+        const float *pp = pred + ((long)b * U1 + u) * H + h;
+        const f32x4 e0 = *(const f32x4 *)ep, e1 = *(const f32x4 *)(ep + 4);
+        const f32x4 p0 = *(const f32x4 *)pp, p1 = *(const f32x4 *)(pp + 4);
+        o[0] = pack_bf16(fast_tanh(e0[0] + p0[0]), fast_tanh(e0[1] + p0[1]));
+        o[1] = pack_bf16(fast_tanh(e0[2] + p0[2]), fast_tanh(e0[3] + p0[3]));
+        o[2] = pack_bf16(fast_tanh(e1[0] + p1[0]), fast_tanh(e1[1] + p1[1]));
+        o[3] = pack_bf16(fast_tanh(e1[2] + p1[2]), fast_tanh(e1[3] + p1[3]));
     }
     hid[idx] = o;
 }
@@ -127,9 +131,9 @@ size_t bf16_wpack_dh_bytes(int V) { return (size_t)(V / 32) * 2 * 16 * 64 * 16; 
 
 void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
 {
-    const long nh = a.rows_alloc * (a.H / 4);
+    const long nh = a.rows_alloc * (a.H / 8);
     hipLaunchKernelGGL(k_make_hidden_bf16, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
-                       a.enc, a.enc_sb, a.enc_st, a.pred, (u32x2 *)a.hidden, a.B, a.T, a.U1, a.H,
+                       a.enc, a.enc_sb, a.enc_st, a.pred, (u32x4 *)a.hidden, a.B, a.T, a.U1, a.H,
                        a.rows_alloc);
     const long nf = (long)(bf16_wpack_fwd_bytes(a.H, a.V) / 16);
     hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W,
@@ -147,8 +151,9 @@ void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
 template <int NT>
 struct BStage {
     u32x4 r[NT / 2];
-    __device__ __forceinline__ void load(const u32x4 *wp, long chunk, int wave, int lane)
+    __device__ __forceinline__ void load(const u32x4 *wp, long chunk, int wave, int lane, bool on = true)
     {
+        if (!on) return;  // experiment switch
         const u32x4 *p = wp + chunk * (2 * NT * 64) + (wave * (NT / 2)) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NT / 2; ++i) r[i] = p[i * 64];
@@ -161,15 +166,29 @@ struct BStage {
     }
 };
 
-template <int NT>
+// 2*NT MFMAs of one chunk; B fragments LDS -> VGPR two reads ahead of their MFMA (explicit
+// software pipeline: left alone, hipcc serialises ds_read -> s_waitcnt -> v_mfma).
+template <int NT, int DEPTH>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], u32x4 a0, u32x4 a1, const u32x4 *slot,
                                           int lane)
 {
+    const u32x4 *p = slot + lane;
+    u32x4 b[DEPTH + 1];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < DEPTH; ++i) b[i] = p[i * 64];
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl)
-            acc[tl] = mfma_bf16(s == 0 ? a0 : a1, slot[(s * NT + tl) * 64 + lane], acc[tl]);
+    for (int i = 0; i < 2 * NT; ++i) {
+        if (i + DEPTH < 2 * NT) b[(i + DEPTH) % (DEPTH + 1)] = p[(i + DEPTH) * 64];
+        acc[i % NT] = mfma_bf16(i < NT ? a0 : a1, b[i % (DEPTH + 1)], acc[i % NT]);
+    }
+    // pin the interleave: DEPTH reads up front, then (1 MFMA, 1 read) pairs
+    __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * NT - DEPTH; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -183,6 +202,10 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
 {
     constexpr int NT = 8;
     __shared__ __attribute__((aligned(16))) u32x4 s_b[2][2 * NT * 64];
+    __shared__ float s_den[128];
+    // per-lane running (max, sum exp) of each of its 16 row-slots, parked in LDS between the
+    // pass epilogues (32 registers the main loop needs for its fragment pipeline)
+    __shared__ float s_stat[2][16][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, half = lane >> 5;
@@ -198,6 +221,9 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
     for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
+
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s_stat[0][r][tid] = RNNT_NEG_INF; s_stat[1][r][tid] = 0.f; }
 
     u32x4 ar[4][2];
     BStage<NT> bx, by;  // even / odd chunks
@@ -215,30 +241,50 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         for (int q = 0; q < 4; ++q) {
             // stage chunk cc+q+1 into the other slot, fetch chunk cc+q+3
             const long nxt = cc + q + 3 < NC ? cc + q + 3 : NC - 1;
-            if (q & 1) { bx.store(s_b[0], wave, lane); bx.load(wp, nxt, wave, lane); }
-            else       { by.store(s_b[1], wave, lane); by.load(wp, nxt, wave, lane); }
+            if (q & 1) { bx.store(s_b[0], wave, lane); bx.load(wp, nxt, wave, lane, !(a.flags & 2048)); }
+            else       { by.store(s_b[1], wave, lane); by.load(wp, nxt, wave, lane, !(a.flags & 2048)); }
             // A fragments of chunk cc+q+3 (same rows, k wraps into the next pass)
-            {
+            if (!(a.flags & 4096)) {
                 int c3 = c + q + 3; if (c3 >= KC) c3 -= KC;
                 ar[(q + 3) & 3][0] = ap[4 * c3];
                 ar[(q + 3) & 3][1] = ap[4 * c3 + 1];
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk<NT>(acc, ar[q][0], ar[q][1], s_b[q & 1], lane);
-            if (q == 3 && c + 4 == KC) {  // pass complete (KC % 4 == 0): bias, store, restart
+            if (!(a.flags & 1024)) mma_chunk<NT, 5>(acc, ar[q][0], ar[q][1], s_b[q & 1], lane);
+            if (q == 3 && c + 4 == KC) {  // pass complete (KC % 4 == 0): bias, store, softmax statistics
+                const bool g1 = 256 * pass + 128 < V;  // V % 128 == 0: a 128-column group is all in or out
+                const int col0 = 256 * pass + 4 * j;
+                const f32x4 b0 = *(const f32x4 *)(a.bias + col0);
+                const f32x4 b1 = *(const f32x4 *)(a.bias + (g1 ? col0 + 128 : col0));
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const int col0 = 256 * pass + 128 * g + 4 * j;
-                    if (col0 < V) {
-                        const f32x4 b4 = *(const f32x4 *)(a.bias + col0);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            f32x4 o = {acc[4 * g][r] + b4[0], acc[4 * g + 1][r] + b4[1],
-                                       acc[4 * g + 2][r] + b4[2], acc[4 * g + 3][r] + b4[3]};
-                            *(f32x4 *)(a.logits + orow * V + col0) = o;
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const f32x4 o0 = {acc[0][r] + b0[0], acc[1][r] + b0[1], acc[2][r] + b0[2], acc[3][r] + b0[3]};
+                    f32x4 o1 = {acc[4][r] + b1[0], acc[5][r] + b1[1], acc[6][r] + b1[2], acc[7][r] + b1[3]};
+                    if (!(a.flags & 256)) {
+                        *(f32x4 *)(a.logits + orow * V + col0) = o0;
+                        if (g1) *(f32x4 *)(a.logits + orow * V + col0 + 128) = o1;
                     }
+                    if (!g1) o1 = o0;  // duplicates only feed the max; their exp terms are dropped below
+                    if (a.flags & 512) continue;
+                    // running (max, sum exp) of this lane's columns of row-slot r
+                    const float lmax = fmaxf(fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3])),
+                                             fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                    const float m_old = s_stat[0][r][tid];
+                    const float mn = fmaxf(m_old, lmax);
+                    const float nm2 = -mn * RNNT_LOG2E;
+                    float e = s_stat[1][r][tid] * __builtin_amdgcn_exp2f(fmaf(m_old, RNNT_LOG2E, nm2));
+                    e += (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) +
+                          __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                         (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) +
+                          __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                    if (g1)
+                        e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) +
+                              __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                             (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) +
+                              __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                    s_stat[1][r][tid] = e;
+                    s_stat[0][r][tid] = mn;
                 }
 #pragma unroll
                 for (int tl = 0; tl < NT; ++tl)
@@ -249,6 +295,45 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         }
         c += 4;
         if (c == KC) { c = 0; ++pass; }
+    }
+
+    // ---- log-softmax denominators and the two log-probs each lattice cell needs.
+    // Row-slot r of half h is row (r&3) + 8*(r>>2) + 4h of the wave's 32; its 32 lanes combine.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float m_l = s_stat[0][r][tid];
+        const float M = half_max(m_l);
+        const float S = half_sum(s_stat[1][r][tid] * __builtin_amdgcn_exp2f((m_l - M) * RNNT_LOG2E));
+        if (j == 0) s_den[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = M + __logf(S);
+    }
+    // lane L: row L&31; lanes 0-31 fetch logit[blank], lanes 32-63 logit[label].  Both were
+    // stored by THIS wave: wait for the stores, then read through L2 (agent-scope loads bypass
+    // the CU's vector L1).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const long cell = row0 + j;
+    if (cell < (long)a.B * a.T * a.U1) {
+        const int U1 = a.U1, T = a.T;
+        const int u = (int)(cell % U1);
+        const long bt = cell / U1;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int Ub = a.target_lens[b];
+        if (t < a.logit_lens[b] && u <= Ub) {
+            const float den = s_den[wave * 32 + j];
+            const float *lrow = a.logits + cell * V;
+            const long si = skew_index(b, t, u, a.D, U1);
+            if (half == 0) {
+                const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.denom_s[si] = den;
+                a.lpb_s[si] = lb - den;
+            } else {
+                float le = 0.f;
+                if (u < Ub) {
+                    const int y = a.targets[(long)b * (U1 - 1) + u];
+                    le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                }
+                a.lpe_s[si] = le;
+            }
+        }
     }
 }
 
@@ -359,9 +444,9 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
                 a0[e] = pack_bf16(g[2 * e], g[2 * e + 1]);
                 a1[e] = pack_bf16(g[8 + 2 * e], g[8 + 2 * e + 1]);
             }
-            if (pexists) { grow[4 * c] = a0; grow[4 * c + 1] = a1; }
+            if (pexists && !(a.flags & 256)) { grow[4 * c] = a0; grow[4 * c + 1] = a1; }
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk<NT>(acc, a0, a1, s_b[q & 1], lane);
+            mma_chunk<NT, 5>(acc, a0, a1, s_b[q & 1], lane);
             lds_barrier();
         }
     }
@@ -369,6 +454,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
     // ---- epilogue.  C layout: accumulator register r of tile 4g+q holds row
     // (r&3) + 8*(r>>2) + 4*half of the wave's 32 rows = (t-row r>>3, u (r&3)+8*((r>>2)&1)+4*half),
     // column 128g + 4j + q.
+    if (a.flags & 8192) return;
     float *s_red = (float *)s_b;  // [4 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
 #pragma unroll
@@ -441,32 +527,33 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
 
 // ---------------------------------------------------------------------------------------
 // k_dw_bf16: dW[v,h] = sum_c G[c,v] hidden[c,h] (split-K slabs), db[v] = sum_c G[c,v].
-// 4 waves = 2 (M) x 2 (N), workgroup tile 256 v x 256 h, wave 128 x 128 = 16 tiles.  Both
-// operands are row-major with K (the cell) as the ROW, the MFMA wants 8 consecutive k per
-// lane: a lane loads, for its 8 cells, 4 adjacent columns (8 B) and transposes the 8 x 4
-// block in registers with 16 v_perm_b32 — the 4 columns are its 4 interleaved tiles.
-// The bias gradient rides the matrix pipe: one extra B fragment of ones (column 0).
+// 4 waves = 2 (M) x 2 (N), workgroup tile 256 v x 256 h, wave 128 x 128 = 16 tiles (256
+// accumulator registers).  Both operands are row-major with K (the cell) as the ROW while the
+// MFMA wants 8 consecutive k per lane, so they go through LDS and come back transposed:
+//  * HBM -> LDS by LDS-DMA (no VGPRs), 4-stage ring of 32 cells x (256 v + 256 h) = 32 KiB,
+//    three stages in flight (96 KiB per CU); wave w fills operand tile w ([32 cells][128 cols]);
+//  * LDS -> VGPR by ds_read_b64_tr_b16 (hardware 4x16 transpose read, cdna_hip_programming.md
+//    T10): two reads give a lane its 8 consecutive cells of one column = the MFMA fragment;
+//  * tile image (b) of T10: 256-byte rows, 16-byte chunk ch of row r at 16*(ch ^ swz(r)),
+//    swz(r) = ((r&3)<<2) | ((r>>2)&3).  The DMA writes LDS linearly, so the swizzle is applied
+//    on the SOURCE side: LDS chunk position p of row r is fetched from global chunk p ^ swz(r).
+// The only vector-memory instructions in the loop are the DMAs, so one counted
+// s_waitcnt vmcnt(16) + one barrier per stage publishes a stage.
+// The bias gradient rides the matrix pipe: an extra B fragment of ones (column 0).
 // ---------------------------------------------------------------------------------------
-#define BW_RING 4  // k-steps (16 cells each) of raw operands in flight per wave
-
-__device__ __forceinline__ void transpose8x4(const u32x2 (&d)[8], u32x4 (&f)[4])
-{
-    // d[i] = cell i: {col0,col1}, {col2,col3};  f[q] = column q: cells {0,1},{2,3},{4,5},{6,7}
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f[0][p] = __builtin_amdgcn_perm(d[2 * p + 1][0], d[2 * p][0], 0x05040100u);
-        f[1][p] = __builtin_amdgcn_perm(d[2 * p + 1][0], d[2 * p][0], 0x07060302u);
-        f[2][p] = __builtin_amdgcn_perm(d[2 * p + 1][1], d[2 * p][1], 0x05040100u);
-        f[3][p] = __builtin_amdgcn_perm(d[2 * p + 1][1], d[2 * p][1], 0x07060302u);
-    }
-}
+#define BW_ROWS 32   // cells per stage (2 MFMA k-steps)
+#define BW_NST 4     // ring stages
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i16x4 *lds_i16x4_ptr;
+typedef __attribute__((address_space(3))) void *lds_vptr;
 
 __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 {
+    extern __shared__ __attribute__((aligned(1024))) char s_ring[];  // BW_NST x 4 tiles x 8 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int i = lane & 31, half = lane >> 5;
+    const int half = lane >> 5;
     const int H = a.H, V = a.V;
     const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
     const int tiles = n_vblk * n_hblk;
@@ -478,98 +565,169 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
     }
     const int tile = id % tiles, split = id / tiles;
     const int vb = tile / n_hblk, hb = tile % n_hblk;
-    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
-    const int vbase = v0 + 4 * i, hbase = h0 + 4 * i;
-    const bool vok = vbase < V, hok = hbase < H;
-    const long nchunk = a.rows_pad / 16;
-    const long k_lo = nchunk * split / a.n_split, k_hi = nchunk * (split + 1) / a.n_split;
-    const long nstep = k_hi - k_lo;  // k-steps of 16 cells
+    const long nstage_all = a.rows_pad / BW_ROWS;
+    const long k_lo = nstage_all * split / a.n_split, k_hi = nstage_all * (split + 1) / a.n_split;
+    const long nstage = k_hi - k_lo;
 
     f32x16 acc[4][4];
-    f32x16 accb[2];
 #pragma unroll
     for (int qm = 0; qm < 4; ++qm)
 #pragma unroll
         for (int qn = 0; qn < 4; ++qn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accb[0][r] = 0.f; accb[1][r] = 0.f; }
-    const bool do_b = hb == 0;  // workgroup-uniform: these workgroups also produce db
-    const unsigned one2 = i == 0 ? 0x3f803f80u : 0u;
-    const u32x4 ones = {one2, one2, one2, one2};
+    // db: the waves with wn == 0 of the hb == 0 workgroups add up their G fragments (v_dot2 with
+    // a pair of ones: 16 VALU per k-step); a 17th accumulator tile would not fit the 256 AGPRs
+    const bool do_b = hb == 0 && wn == 0;  // wave-uniform
+    float dbl[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned one_pair_u = 0x3f803f80u;  // (1.0bf16, 1.0bf16)
 
-    if (nstep > 0) {
-        // G rows are 4V bytes apart (bf16 in the first half of the fp32 logits row)
-        const char *gp = (const char *)a.logits + (k_lo * 16 + 8 * half) * (long)V * 4 + (vok ? vbase : V - 4) * 2L;
-        const char *hp = (const char *)a.hidden + (k_lo * 16 + 8 * half) * (long)H * 2 + (hok ? hbase : H - 4) * 2L;
-        const long grow = 4L * V, hrow = 2L * H;
-        u32x2 ra[BW_RING][8], rb[BW_RING][8];
+    if (nstage > 0) {
+        // ---- DMA source of this wave's operand tile: wave 0/1 -> G column halves, 2/3 -> hidden
+        const bool is_g = wave < 2;
+        int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
+        if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
+        const long rstride = is_g ? 4L * V : 2L * H;  // bytes between cells (G sits in fp32 logits rows)
+        const char *src = (is_g ? (const char *)a.logits : (const char *)a.hidden) +
+                          (k_lo * BW_ROWS) * rstride + 2L * col0;
+        // DMA i (0..7) of a stage: rows 4i .. 4i+3; lane L: row 4i + (L>>4), LDS chunk position L&15
+        // <- global chunk (L&15) ^ swz(row), swz = ((L>>4)<<2) | (i&3)
+        int soff[8];
 #pragma unroll
-        for (int s_ = 0; s_ < BW_RING; ++s_) {
+        for (int i = 0; i < 8; ++i)
+            soff[i] = (int)((4 * i + (lane >> 4)) * rstride) + 16 * ((lane & 15) ^ (((lane >> 4) << 2) | (i & 3)));
+        auto dma_stage = [&](long st, int slot) {
+            const char *p = src + st * (BW_ROWS * rstride);
+            char *dst = s_ring + slot * 32768 + wave * 8192;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ra[s_][e] = *(const u32x2 *)(gp + e * grow);
-                rb[s_][e] = *(const u32x2 *)(hp + e * hrow);
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_global_load_lds((const void *)(p + soff[i]), (lds_vptr)(dst + 1024 * i), 16, 0, 0);
+        };
+        // ---- transposed fragment reads.  Fragment of 32-column tile m, k-step ks: lane
+        // (g = lane>>4, q = (lane&15)>>2, p = lane&3) reads rows 16ks + 8(g>>1) + 4sec + q at
+        // chunk 4m + 2(g&1) + (p>>1), +8(p&1) bytes, sec = 0,1 (cells 0-3 / 4-7 of its 8).
+        // The reads are inline asm: hipcc guards every LDS read it can see that follows an
+        // LDS-DMA with s_waitcnt vmcnt(0), which would drain the ring each stage.  Their
+        // results are only used after frag_wait(), which names them as in/out operands.
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, hh = g >> 1;
+        int foff[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                const int row = 8 * hh + 4 * sec + q;  // + 16ks
+                const int ch = 4 * m + 2 * (g & 1) + (p >> 1);
+                const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+                foff[m][sec] = 256 * row + 16 * (ch ^ swz) + 8 * (p & 1);
             }
-            gp += 16 * grow;
-            hp += 16 * hrow;
-        }
-        // the buffers carry >= 16*BW_RING zero rows past rows_pad, so the ring may overrun
-        for (long st = 0; st < nstep; st += BW_RING) {
+        const int lds0 = (int)(size_t)(lds_vptr)s_ring;  // LDS byte address of the ring
+        const int a_tile = lds0 + wm * 8192, b_tile = lds0 + 16384 + wn * 8192;
+        auto dma_piece = [&](long st, int slot, int i) {
+            __builtin_amdgcn_global_load_lds((const void *)(src + st * (BW_ROWS * rstride) + soff[i]),
+                                             (lds_vptr)(s_ring + slot * 32768 + wave * 8192 + 1024 * i), 16, 0, 0);
+        };
+        struct Frags { u32x2 al[4], ah[4], bl[4], bh[4]; };
+        auto reads = [&](Frags &f, int slot, int ks) {  // 16 transposed reads, NOT waited for
+            if (a.flags & 4096) return;  // experiment switch
 #pragma unroll
-            for (int s_ = 0; s_ < BW_RING; ++s_) {
-                if (st + s_ < nstep) {  // workgroup-uniform
-                    u32x4 fa[4], fb[4];
-                    transpose8x4(ra[s_], fa);
-                    transpose8x4(rb[s_], fb);
+            for (int m = 0; m < 4; ++m) {
+                const int a0 = a_tile + slot * 32768 + 4096 * ks, b0 = b_tile + slot * 32768 + 4096 * ks;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.al[m]) : "v"(a0 + foff[m][0]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.ah[m]) : "v"(a0 + foff[m][1]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.bl[m]) : "v"(b0 + foff[m][0]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.bh[m]) : "v"(b0 + foff[m][1]));
+            }
+        };
+        auto landed = [&](Frags &f, bool wait) {  // every later use of f depends on this point
+            if (wait)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.al[2]), "+v"(f.al[3]), "+v"(f.ah[0]),
+                               "+v"(f.ah[1]), "+v"(f.ah[2]), "+v"(f.ah[3])
+                             :: "memory");
+            else
+                asm volatile("" : "+v"(f.al[0]), "+v"(f.al[1]), "+v"(f.al[2]), "+v"(f.al[3]), "+v"(f.ah[0]),
+                                  "+v"(f.ah[1]), "+v"(f.ah[2]), "+v"(f.ah[3]));
+            asm volatile("" : "+v"(f.bl[0]), "+v"(f.bl[1]), "+v"(f.bl[2]), "+v"(f.bl[3]), "+v"(f.bh[0]),
+                              "+v"(f.bh[1]), "+v"(f.bh[2]), "+v"(f.bh[3]));
+        };
+        // 16 MFMAs of one k-step with 4 DMA pieces of stage `dst` threaded through them (a DMA
+        // costs ~60 issue cycles: issued in one block they stall the matrix pipe)
+        auto mma_step = [&](const Frags &f, long dst, int dslot, int piece0) {
+            u32x4 fa[4], fb[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        ra[s_][e] = *(const u32x2 *)(gp + e * grow);
-                        rb[s_][e] = *(const u32x2 *)(hp + e * hrow);
-                    }
-                    gp += 16 * grow;
-                    hp += 16 * hrow;
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < 4; ++m) {
+                fa[m] = u32x4{f.al[m][0], f.al[m][1], f.ah[m][0], f.ah[m][1]};
+                fb[m] = u32x4{f.bl[m][0], f.bl[m][1], f.bh[m][0], f.bh[m][1]};
+            }
 #pragma unroll
-                    for (int qm = 0; qm < 4; ++qm)
+            for (int qm = 0; qm < 4; ++qm) {
+                if (!(a.flags & 1024)) {
 #pragma unroll
-                        for (int qn = 0; qn < 4; ++qn)
-                            acc[qm][qn] = mfma_bf16(fa[qm], fb[qn], acc[qm][qn]);
-                    if (do_b) {
-                        accb[0] = mfma_bf16(wn == 0 ? fa[0] : fa[2], ones, accb[0]);
-                        accb[1] = mfma_bf16(wn == 0 ? fa[1] : fa[3], ones, accb[1]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = mfma_bf16(fa[qm], fb[qn], acc[qm][qn]);
                 }
+                if (!(a.flags & 8192)) dma_piece(dst, dslot, piece0 + qm);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (do_b && !(a.flags & 2048)) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        // (the fdot2_f32_bf16 builtin on a vector element was folded to element 0
+                        // by hipcc 7.2: spelled out instead)
+                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(dbl[m]) : "v"(one_pair_u), "v"(fa[m][e]));
+            }
+        };
+
+        // Pipeline.  B_s = barrier publishing stage s (every wave has landed its share and has
+        // finished reading stage s-1).  After B_s: reads of stage s, DMA of stage s+3 into the
+        // slot of stage s-1.  Fragment reads run one k-step ahead of their MFMAs.
+        dma_stage(0, 0);
+        dma_stage(1, 1);
+        dma_stage(2, 2);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        lds_barrier();  // B_0
+        Frags X, Y;
+        reads(X, 0, 0);
+        landed(X, true);
+        for (long st = 0; st < nstage; ++st) {
+            const int slot = (int)(st & 3);
+            reads(Y, slot, 1);
+            mma_step(X, st + 3, (slot + 3) & 3, 0);
+            // stage st+1: younger in flight = stage st+2 (8 DMAs) + the 4 pieces just issued
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            lds_barrier();  // B_{st+1}; its lgkmcnt(0) also covers Y
+            landed(Y, false);
+            reads(X, (slot + 1) & 3, 0);  // past the last stage: reads a landed, unused slot
+            mma_step(Y, st + 3, (slot + 3) & 3, 4);
+            landed(X, true);  // X is loop-carried: landed before the back-edge, copies are safe
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before exit
     }
 
+    // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r
+    // of tile (qm,qn): v = v0 + 32qm + (r&3) + 8(r>>2) + 4half, h = h0 + 32qn + (lane&31).
+    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
     float *sw = a.slab_w + (long)split * V * H;
-    if (hok) {
 #pragma unroll
-        for (int qm = 0; qm < 4; ++qm)
+    for (int qm = 0; qm < 4; ++qm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int v = v0 + 4 * row + qm;
-                if (v < V) {
-                    f32x4 o = {acc[qm][0][r], acc[qm][1][r], acc[qm][2][r], acc[qm][3][r]};
-                    *(f32x4 *)(sw + (long)v * H + hbase) = o;
+        for (int r = 0; r < 16; ++r) {
+            const int v = v0 + 32 * qm + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (v < V) {
+#pragma unroll
+                for (int qn = 0; qn < 4; ++qn) {
+                    const int h = h0 + 32 * qn + (lane & 31);
+                    if (h < H) sw[(long)v * H + h] = acc[qm][qn][r];
                 }
             }
-    }
-    if (do_b && i == 0) {  // column 0 of the ones product: lanes 0 and 32
+        }
+    if (do_b) {  // lane (v = l&31, half) summed the cells 8*half .. 8*half+7 of every k-step
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int qm = 2 * wn + k;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int v = v0 + 4 * row + qm;
-                if (v < V) a.slab_b[(long)split * V + v] = accb[k][r];
-            }
+        for (int m = 0; m < 4; ++m) {
+            const float t = dbl[m] + __shfl_xor(dbl[m], 32, 64);
+            const int v = v0 + 32 * m + (lane & 31);
+            if (half == 0 && v < V) a.slab_b[(long)split * V + v] = t;
         }
     }
 }
@@ -577,5 +735,10 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 void launch_dw_bf16(const Bf16Args &a, hipStream_t st)
 {
     const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
-    hipLaunchKernelGGL(k_dw_bf16, dim3(tiles * a.n_split), dim3(256), 0, st, a);
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per process
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_dw_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, BW_NST * 32768);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_dw_bf16, dim3(tiles * a.n_split), dim3(256), BW_NST * 32768, st, a);
 }

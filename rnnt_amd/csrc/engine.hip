@@ -57,14 +57,16 @@ int dw_splits(int B, int T, int H, int V)
     return (int)s;
 }
 
-long bf16_rows_alloc(size_t rows_pad) { return (long)((rows_pad + 64 + 127) / 128 * 128); }
+// forward row tiles of 128; the dW DMA ring over-reads up to 96 (zero) rows past rows_pad
+long bf16_rows_alloc(size_t rows_pad) { return (long)((rows_pad + 96 + 127) / 128 * 128); }
 
 void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout *L)
 {
     const size_t D = (size_t)T + U1 - 1;
     const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
     // G / hidden rows are padded with >= 1 zero row up to a multiple of 16 (dW chunk size)
-    const size_t rows_pad = (cells + 1 + 15) / 16 * 16;  // buffers get 16 more rows (dW ring overrun)
+    // (bf16 route: multiple of 32 = one dW stage)
+    const size_t rows_pad = dtype == RNNT_DTYPE_BF16 ? (cells + 1 + 31) / 32 * 32 : (cells + 1 + 15) / 16 * 16;
     L->rows_pad = rows_pad;
     L->D = (int)D;
     L->n_ublk = (U1 + 15) / 16;
@@ -72,7 +74,6 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->n_split = dw_splits(B, T, H, V);
     size_t o = 0;
     if (dtype == RNNT_DTYPE_BF16) {
-        // row tiles of 128 for the forward GEMM; the dW ring over-reads 64 (zero) rows
         const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
         L->logits = o;   o += align_up(ra * V * 4);
         L->hidden = o;   o += align_up(ra * H * 2);
@@ -189,17 +190,15 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         h.hidden = (unsigned short *)(ws + L.hidden);
         h.wpack_fwd = ws + L.wpack; h.wpack_dh = ws + L.wpack + align_up(bf16_wpack_fwd_bytes(H, V));
         h.logits = logits; h.coef = coef; h.logit_lens = logit_lens;
+        h.targets = targets; h.target_lens = target_lens;
+        h.denom_s = denom_s; h.lpb_s = lpb_s; h.lpe_s = lpe_s; h.D = L.D;
         h.slab_enc = g.slab_enc; h.slab_pred = g.slab_pred; h.slab_w = g.slab_w; h.slab_b = g.slab_b;
         h.rows_pad = (long)L.rows_pad; h.rows_alloc = bf16_rows_alloc(L.rows_pad);
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
-        h.n_ublk = L.n_ublk; h.n_split = L.n_split;
+        h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = g_flags;
         g.flags |= 16;  // reductions: dPred slabs are 8 t-rows high, as in k_dhidden_gen
         if (stages & ST_PROD) launch_bf16_producers(h, st);
-        if (stages & ST_FWD) {
-            launch_joint_fwd_bf16(h, st);
-            launch_logsoftmax_gather(logits, targets, logit_lens, target_lens, denom_s, lpb_s, lpe_s,
-                                     B, T, U1, V, L.D, blank, st);
-        }
+        if (stages & ST_FWD) launch_joint_fwd_bf16(h, st);  // softmax statistics in its epilogue
         if (stages & ST_LATTICE)
             launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D, st);
         if (stages & ST_COEF)

@@ -309,7 +309,11 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
             for (int g = 0; g < 2; ++g) w[s_][g] = *(const f32x4 *)(wptr[g] + (long)(8 * cc + s_) * H);
     };
-    auto xload = [&](int c8) { return *(const f32x4 *)(xsrc + xstep * (c8 < VK ? c8 : VK - 1)); };
+    const bool xp_nold = (a.flags & 4096) != 0, xp_nost = (a.flags & 256) != 0;  // experiment switches
+    auto xload = [&](int c8) {
+        if (xp_nold) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *(const f32x4 *)(xsrc + xstep * (c8 < VK ? c8 : VK - 1));
+    };
 
     f32x4 xr[4];           // raw logits of chunks c+1 .. c+4 (ring, slot = chunk & 3)
     f32x4 wf[2][4][2];     // W fragments of chunks c, c+1 (slot = chunk & 1)
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             if (c8 + 1 < VK) {
                 const f32x4 gn = gen(xr[(j + 1) & 3], c8 + 1);
                 *(f32x4 *)(smem + ((j + 1) & 1) * 1024 + wave * 256 + 4 * lane) = gn;
-                if (pexists) *(f32x4 *)(lptr + 8 * (c8 + 1)) = gn;
+                if (pexists && !xp_nost) *(f32x4 *)(lptr + 8 * (c8 + 1)) = gn;
             }
             xr[(j + 1) & 3] = xload(c8 + 5);
             f32x4 cur[4][2];
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     }
 
     // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
+    if (a.flags & 8192) return;  // experiment switch
     float psum[8][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)

@@ -78,12 +78,15 @@ struct Bf16Args {
     void *wpack_fwd, *wpack_dh;
     float *logits;       // fp32 [rows_alloc,V]; G (bf16) overwrites the first half of each row
     const CellCoef *coef;
-    const int32_t *logit_lens;
+    const int32_t *targets, *logit_lens, *target_lens;
+    float *denom_s, *lpb_s, *lpe_s;  // skewed [B,D,U1] softmax statistics (forward epilogue)
+    int D;
     float *slab_enc, *slab_pred, *slab_w, *slab_b;
-    long rows_alloc;     // multiple of 128, >= rows_pad + 64; rows >= B*T*U1 are zero
-    long rows_pad;       // K extent of the dW GEMM (multiple of 16)
+    long rows_alloc;     // multiple of 128, >= rows_pad + 96; rows >= B*T*U1 are zero
+    long rows_pad;       // K extent of the dW GEMM (multiple of 32)
     int B, T, U1, H, V, blank;
     int n_ublk, n_split;
+    int flags;  // experiment switches (bits 8..: 256 no stores, 512 no statistics, 1024 no MFMA)
 };
 size_t bf16_wpack_fwd_bytes(int H, int V);
 size_t bf16_wpack_dh_bytes(int V);

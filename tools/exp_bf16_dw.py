@@ -1,0 +1,24 @@
+"""Experiment: bf16 dW stage with / without MFMA (valid G in the workspace)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synth
+from rnnt_amd import engine
+B, T, U, H, V = 32, 1000, 200, 512, 1024
+enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
+outs = engine.alloc_fused_outputs(enc, pred, W)
+def run(stage): engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V-1, 1/B, outs=outs, stage=stage, dtype="bf16")
+for s in range(8): run(s)
+def timeit(stage, n=5):
+    run(stage); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): run(stage)
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n
+for flags, name in ((0, "normal"), (1024, "no MFMA"), (2048, "no dot2"), (4096, "no tr reads"), (8192, "no DMA"),
+                    (1024 + 2048, "no MFMA/dot2"), (1024 + 2048 + 4096, "no MFMA/dot2/reads"),
+                    (1024 + 2048 + 4096 + 8192, "only barriers"), (2048 + 4096 + 8192, "MFMA only")):
+    engine.lib().rnnt_engine_set_flags(flags)
+    print(f"dw {name:20s}: {timeit(6):.2f} ms", flush=True)
+engine.lib().rnnt_engine_set_flags(0)
