@@ -262,8 +262,14 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
                     const f32x4 o0 = {acc[0][r] + b0[0], acc[1][r] + b0[1], acc[2][r] + b0[2], acc[3][r] + b0[3]};
                     f32x4 o1 = {acc[4][r] + b1[0], acc[5][r] + b1[1], acc[6][r] + b1[2], acc[7][r] + b1[3]};
                     if (!(a.flags & 256)) {
-                        *(f32x4 *)(a.logits + orow * V + col0) = o0;
-                        if (g1) *(f32x4 *)(a.logits + orow * V + col0 + 128) = o1;
+                        if (!(a.flags & 1)) {  // streaming stores: the logits are not re-read by this kernel's CUs
+                                              // and should not evict the A rows the next pass re-reads from L2
+                            __builtin_nontemporal_store(o0, (f32x4 *)(a.logits + orow * V + col0));
+                            if (g1) __builtin_nontemporal_store(o1, (f32x4 *)(a.logits + orow * V + col0 + 128));
+                        } else {
+                            *(f32x4 *)(a.logits + orow * V + col0) = o0;
+                            if (g1) *(f32x4 *)(a.logits + orow * V + col0 + 128) = o1;
+                        }
                     }
                     if (!g1) o1 = o0;  // duplicates only feed the max; their exp terms are dropped below
                     if (a.flags & 512) continue;

@@ -75,3 +75,25 @@ def test_layout_is_consistent(lib):
     assert L.D == 17 + 9 - 1 and L.n_ublk == 1 and L.n_ttile == 5
     assert L.rows_pad % 16 == 0 and L.rows_pad > 3 * 17 * 9
     assert L.total == engine.workspace_bytes(3, 17, 9, 64, 32)
+
+
+def test_bf16_dtype_queries_and_validation(lib):
+    """RNNT_DTYPE_BF16 (include/rnnt_engine.h): fused entry only, H % 128, H <= 512, V % 128."""
+    from rnnt_amd import engine
+    lib.rnnt_engine_last_error.restype = ctypes.c_char_p
+    n = ctypes.c_size_t(0)
+    assert lib.rnnt_engine_workspace_bytes(32, 1000, 201, 512, 1024, 1, ctypes.byref(n)) == 0
+    f32 = engine.workspace_bytes(32, 1000, 201, 512, 1024, "fp32")
+    assert n.value == engine.workspace_bytes(32, 1000, 201, 512, 1024, "bf16") < f32  # bf16 hidden
+    for H, V in ((64, 128), (640, 1024), (512, 1000)):
+        assert lib.rnnt_engine_workspace_bytes(2, 5, 3, H, V, 1, ctypes.byref(n)) == -2
+        assert b"RNNT_DTYPE_BF16" in lib.rnnt_engine_last_error()
+    # the standalone loss / joint entries have no bf16 variant
+    assert lib.rnnt_engine_loss_workspace_bytes(2, 5, 3, 128, 1, ctypes.byref(n)) == -2
+    L = engine.layout(3, 17, 9, 128, 256, "bf16")
+    assert L.rows_pad % 32 == 0 and L.rows_pad > 3 * 17 * 9
+    assert engine.dtype_code("bf16") == engine.DTYPE_BF16 == 1 and engine.dtype_code("fp32") == 0
+    import torch
+    assert engine.dtype_code(torch.bfloat16) == 1
+    with pytest.raises(ValueError):
+        engine.dtype_code("fp8")

@@ -121,3 +121,24 @@ def test_closed_form_uniform_lattice():
         ref = lgamma_paths_cost(Tb, Ub, lp[V - 1], lp[tg[b, :Ub]].sum())
         assert abs(r["costs"][b] - ref) < 1e-9
     assert np.abs(r["grad_enc"]).max() == 0 and abs(r["grad_bias"].sum()) < 1e-12
+
+
+def test_bf16_rounding_point_oracle_is_close_to_exact():
+    """The bf16 route's checker (tests/helpers.oracle_fused_bf16) rounds tanh(enc+pred), W and
+    the logits gradient to bf16; it must stay within bf16's error of the exact oracle, and its
+    rounding helper must be round-to-nearest-even on the fp32 bit pattern."""
+    import numpy as np
+    from tests.helpers import (BF16_GRAD_RTOL_EXACT, BF16_LOSS_RTOL_EXACT, assert_close_grad,
+                               assert_close_loss, bf16_round, make_inputs, oracle_fused,
+                               oracle_fused_bf16)
+    x = np.array([1.0, 1.00390625, 1.005859375, -3.140625, 1.00390625 + 2 ** -9], dtype=np.float32)
+    r = bf16_round(x)
+    assert (r.view(np.uint32) & 0xFFFF == 0).all()
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == 1.0078125  # tie -> even, above tie -> up
+    assert r[4] == 1.0078125
+    d = make_inputs(2, 9, 4, 128, 128, seed=11)
+    a, b = oracle_fused_bf16(d), oracle_fused(d)
+    assert_close_loss("loss", a["loss"], b["loss"], rtol=BF16_LOSS_RTOL_EXACT)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, a[k], b[k], rtol=BF16_GRAD_RTOL_EXACT)
+        assert np.abs(a[k] - b[k]).max() > 0  # the rounding really happens

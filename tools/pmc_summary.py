@@ -18,7 +18,7 @@ for r in rows:
         continue
     by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in sorted(by.items()):
-    if not any(x in k for x in ("k_joint_fwd", "k_dhidden", "k_dw", "k_lattice")):
+    if not any(x in k for x in ("k_joint_fwd", "k_dhidden", "k_dw", "k_lattice", "k_make_hidden")):
         continue
     print(k)
     for n, v in sorted(c.items()):
