@@ -327,6 +327,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         xr[0] = xload(4);
     }
     __syncthreads();
+    // One MFMA of the chunk: number m (0..15) of k-step s_.  PIN() keeps what the source puts
+    // between two MFMAs there: the matrix pipe runs an MFMA for 64 cycles while issuing it takes
+    // a few, so the chunk's other work (producing the next chunk's G, copying / refilling the W
+    // ring, LDS and memory traffic) rides in those gaps instead of standing in front of the 64
+    // MFMAs (where it cost ~450 of every ~4800 cycles).
+#define PIN() __builtin_amdgcn_sched_barrier(0)
     for (int c0 = 0; c0 < VK; c0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -334,40 +340,90 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             const float *gb = smem + (j & 1) * 1024;
             const f32x4 a0 = *(const f32x4 *)(gb + (2 * wm) * 256 + 4 * lane);
             const f32x4 a1 = *(const f32x4 *)(gb + (2 * wm + 1) * 256 + 4 * lane);
-            // produce chunk c8+1 (its logits were requested three chunks ago)
-            if (c8 + 1 < VK) {
-                const f32x4 gn = gen(xr[(j + 1) & 3], c8 + 1);
-                *(f32x4 *)(smem + ((j + 1) & 1) * 1024 + wave * 256 + 4 * lane) = gn;
-                if (pexists && !xp_nost) *(f32x4 *)(lptr + 8 * (c8 + 1)) = gn;
-            }
-            xr[(j + 1) & 3] = xload(c8 + 5);
             f32x4 cur[4][2];
+            cur[0][0] = wf[j & 1][0][0];
+            cur[0][1] = wf[j & 1][0][1];
+            PIN();
+            auto mf = [&](int s_, int m) {
+                const int mt = m >> 3, g = (m >> 2) & 1, q = m & 3;
+                const float gv = mt == 0 ? a0[s_] : a1[s_];
+                acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, cur[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
+            };
+            // ---- k-step 0, with the production of chunk c8+1 (logits requested 3 chunks ago)
+            const bool produce = c8 + 1 < VK;  // workgroup-uniform
+            const int cn = c8 + 1, vbn = 8 * cn + 4 * half;
+            f32x4 gn;
+            {
+                const f32x4 &x = xr[(j + 1) & 3];
+                mf(0, 0); cur[1][0] = wf[j & 1][1][0]; PIN();
+                mf(0, 1); cur[1][1] = wf[j & 1][1][1]; PIN();
+                mf(0, 2);
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_)
+                for (int e = 0; e < 4; ++e) { gn[e] = fmaf(x[e], RNNT_LOG2E, cf.c1); asm volatile("" : "+v"(gn[e])); }
+                PIN();
+                mf(0, 3);
+                gn[0] = __builtin_amdgcn_exp2f(gn[0]); gn[1] = __builtin_amdgcn_exp2f(gn[1]);
+                asm volatile("" : "+v"(gn[0]), "+v"(gn[1]));
+                PIN();
+                mf(0, 4);
+                gn[2] = __builtin_amdgcn_exp2f(gn[2]); gn[3] = __builtin_amdgcn_exp2f(gn[3]);
+                asm volatile("" : "+v"(gn[2]), "+v"(gn[3]));
+                PIN();
+                mf(0, 5);
+                {
+                    const unsigned dy = (unsigned)(cf.y - vbn);
+                    if (__any(dy < 4u)) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) cur[s_][g] = wf[j & 1][s_][g];
-            wload(wf[j & 1], c8 + 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const float gv = mt == 0 ? a0[s_] : a1[s_];
-#pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                gv, cur[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e)
+                            if (dy == (unsigned)e) gn[e] -= cf.se;
+                    }
                 }
-            __builtin_amdgcn_sched_barrier(0);
+                PIN();
+                mf(0, 6);
+                if (8 * cn <= a.blank && a.blank < 8 * cn + 8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (vbn + e == a.blank) gn[e] -= cf.sb;
+                }
+                PIN();
+                mf(0, 7);
+                if (produce) {
+                    *(f32x4 *)(smem + ((j + 1) & 1) * 1024 + wave * 256 + 4 * lane) = gn;
+                    if (pexists && !xp_nost) *(f32x4 *)(lptr + 8 * cn) = gn;
+                }
+                PIN();
+                mf(0, 8);
+                xr[(j + 1) & 3] = xload(c8 + 5);
+                PIN();
+#pragma unroll
+                for (int m = 9; m < 16; ++m) mf(0, m);
+                PIN();
+            }
+            // ---- k-step 1, with the rest of the W ring copies
+            mf(1, 0); cur[2][0] = wf[j & 1][2][0]; PIN();
+            mf(1, 1); cur[2][1] = wf[j & 1][2][1]; PIN();
+            mf(1, 2); cur[3][0] = wf[j & 1][3][0]; PIN();
+            mf(1, 3); cur[3][1] = wf[j & 1][3][1]; PIN();
+#pragma unroll
+            for (int m = 4; m < 16; ++m) mf(1, m);
+            PIN();
+            // ---- k-steps 2, 3; the ring slot is copied out: refill it with chunk c8+2
+            mf(2, 0);
+            wload(wf[j & 1], c8 + 2);
+            PIN();
+#pragma unroll
+            for (int m = 1; m < 16; ++m) mf(2, m);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) mf(3, m);
+            PIN();
             // publish chunk c8+1's fragments / free chunk c8's buffer.  Raw barrier: a
             // __syncthreads() would add s_waitcnt vmcnt(0) and drain the logits / W prefetch.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            PIN();
         }
     }
+#undef PIN
 
     // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
     if (a.flags & 8192) return;  // experiment switch
