@@ -233,8 +233,8 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
 #define DG_BT 8
 __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 4 * 256 + 2 * 64 * 65];
-    float(*s_red)[64][65] = (float(*)[64][65])(smem + 2 * 4 * 256);
+    __shared__ __attribute__((aligned(16))) float smem[4 * 4 * 256 + 2 * 64 * 65];  // 4-slot G exchange + epilogue
+    float(*s_red)[64][65] = (float(*)[64][65])(smem + 4 * 4 * 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -315,18 +315,24 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         return *(const f32x4 *)(xsrc + xstep * (c8 < VK ? c8 : VK - 1));
     };
 
-    f32x4 xr[4];           // raw logits of chunks c+1 .. c+4 (ring, slot = chunk & 3)
+    f32x4 xr[4];           // raw logits of chunks c+2 .. c+5 (ring, slot = chunk & 3)
     f32x4 wf[2][4][2];     // W fragments of chunks c, c+1 (slot = chunk & 1)
     xr[0] = xload(0); xr[1] = xload(1); xr[2] = xload(2); xr[3] = xload(3);
     wload(wf[0], 0);
     wload(wf[1], 1);
-    {
-        const f32x4 g0 = gen(xr[0], 0);
-        *(f32x4 *)(smem + wave * 256 + 4 * lane) = g0;
-        if (pexists) *(f32x4 *)lptr = g0;
-        xr[0] = xload(4);
+    // G is produced TWO chunks ahead of its MFMAs (4-slot LDS exchange, slot = chunk & 3): the
+    // fragments of chunk c+1 are already published while chunk c is multiplied, so they are read
+    // inside chunk c's MFMA stream and no LDS latency stands at the top of a chunk.
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f32x4 gk = gen(xr[k], k);
+        *(f32x4 *)(smem + k * 1024 + wave * 256 + 4 * lane) = gk;
+        if (pexists) *(f32x4 *)(lptr + 8 * k) = gk;
+        xr[k] = xload(4 + k);
     }
     __syncthreads();
+    f32x4 a0 = *(const f32x4 *)(smem + (2 * wm) * 256 + 4 * lane);       // fragments of chunk 0
+    f32x4 a1 = *(const f32x4 *)(smem + (2 * wm + 1) * 256 + 4 * lane);
     // One MFMA of the chunk: number m (0..15) of k-step s_.  PIN() keeps what the source puts
     // between two MFMAs there: the matrix pipe runs an MFMA for 64 cycles while issuing it takes
     // a few, so the chunk's other work (producing the next chunk's G, copying / refilling the W
@@ -337,9 +343,6 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c8 = c0 + j;  // VK % 4 == 0
-            const float *gb = smem + (j & 1) * 1024;
-            const f32x4 a0 = *(const f32x4 *)(gb + (2 * wm) * 256 + 4 * lane);
-            const f32x4 a1 = *(const f32x4 *)(gb + (2 * wm + 1) * 256 + 4 * lane);
             f32x4 cur[4][2];
             cur[0][0] = wf[j & 1][0][0];
             cur[0][1] = wf[j & 1][0][1];
@@ -349,12 +352,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 const float gv = mt == 0 ? a0[s_] : a1[s_];
                 acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, cur[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
             };
-            // ---- k-step 0, with the production of chunk c8+1 (logits requested 3 chunks ago)
-            const bool produce = c8 + 1 < VK;  // workgroup-uniform
-            const int cn = c8 + 1, vbn = 8 * cn + 4 * half;
+            // ---- k-step 0, with the production of chunk c8+2 (logits requested 4 chunks ago)
+            const bool produce = c8 + 2 < VK;  // workgroup-uniform
+            const int cn = c8 + 2, vbn = 8 * cn + 4 * half;
             f32x4 gn;
             {
-                const f32x4 &x = xr[(j + 1) & 3];
+                const f32x4 &x = xr[(j + 2) & 3];
                 mf(0, 0); cur[1][0] = wf[j & 1][1][0]; PIN();
                 mf(0, 1); cur[1][1] = wf[j & 1][1][1]; PIN();
                 mf(0, 2);
@@ -388,12 +391,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 PIN();
                 mf(0, 7);
                 if (produce) {
-                    *(f32x4 *)(smem + ((j + 1) & 1) * 1024 + wave * 256 + 4 * lane) = gn;
+                    *(f32x4 *)(smem + ((j + 2) & 3) * 1024 + wave * 256 + 4 * lane) = gn;
                     if (pexists && !xp_nost) *(f32x4 *)(lptr + 8 * cn) = gn;
                 }
                 PIN();
                 mf(0, 8);
-                xr[(j + 1) & 3] = xload(c8 + 5);
+                xr[(j + 2) & 3] = xload(c8 + 6);
                 PIN();
 #pragma unroll
                 for (int m = 9; m < 16; ++m) mf(0, m);
@@ -404,8 +407,13 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             mf(1, 1); cur[2][1] = wf[j & 1][2][1]; PIN();
             mf(1, 2); cur[3][0] = wf[j & 1][3][0]; PIN();
             mf(1, 3); cur[3][1] = wf[j & 1][3][1]; PIN();
+            mf(1, 4);
+            // fragments of chunk c8+1 (written during chunk c8-1, published by its barrier)
+            const f32x4 an0 = *(const f32x4 *)(smem + ((j + 1) & 3) * 1024 + (2 * wm) * 256 + 4 * lane);
+            const f32x4 an1 = *(const f32x4 *)(smem + ((j + 1) & 3) * 1024 + (2 * wm + 1) * 256 + 4 * lane);
+            PIN();
 #pragma unroll
-            for (int m = 4; m < 16; ++m) mf(1, m);
+            for (int m = 5; m < 16; ++m) mf(1, m);
             PIN();
             // ---- k-steps 2, 3; the ring slot is copied out: refill it with chunk c8+2
             mf(2, 0);
@@ -421,6 +429,8 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             PIN();
+            a0 = an0;
+            a1 = an1;
         }
     }
 #undef PIN
