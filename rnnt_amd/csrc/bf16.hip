@@ -349,21 +349,31 @@ void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------
-// k_dhidden_bf16: G from logits (one thread per cell x 16 vocabulary entries per chunk), G
-// stored as bf16 over the first half of its logits row, dHidden = G . W accumulated over all
-// H <= 512 columns (16 tiles, 256 accumulator registers, one workgroup per CU), epilogue as
-// the fp32 kernel: x (1 - hidden^2), sum over u -> dEnc slab, sum over t -> dPred slab.
-// Tile = 8 t x 16 u cells; wave w owns t-rows 2w, 2w+1.  grid (n_ublk, ceil(T/8), B).
+// k_dhidden_bf16: G from logits, stored as bf16 over the first half of its logits row, and
+// dHidden = G . W over all H <= 512 columns; epilogue as the fp32 kernel: x (1 - hidden^2),
+// sum over u -> dEnc slab, sum over t -> dPred slab.  Tile = 8 t x 16 u cells.
+// 8 waves (two per SIMD, 128 accumulator registers each):
+//  * production: wave w turns t-row w of the tile into G: lane (u = l&15, quarter = l>>4) owns
+//    8 consecutive vocabulary entries per 32-wide chunk (32 B of logits in, 16 B of bf16 out: a
+//    row's four lanes cover its whole 128-B line), one chunk ahead of the MFMAs, and drops its
+//    16 B straight into the MFMA A-fragment image of its M-tile in LDS (double-buffered);
+//  * consumption: wave (wm = w&3, wn = w>>2) multiplies M-tile wm (t-rows 2wm, 2wm+1) by the
+//    column half wn (8 tiles); A fragments from the exchange, B fragments from the staged W
+//    chunk (each wave copies 4 KiB of it L2 -> VGPR -> LDS two chunks ahead).
+// One barrier per chunk publishes both.  grid (n_ublk, ceil(T/8), B), 512 threads.
 // Requires V % 128 == 0, H % 128 == 0, H <= 512.
 // ---------------------------------------------------------------------------------------
 #define BG_BT 8
 #define BG_BU 16
-__global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
+__global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
 {
-    constexpr int NT = 16;
-    __shared__ __attribute__((aligned(16))) u32x4 s_b[2][2 * NT * 64];  // 64 KiB; reused by the epilogue
+    // [0, 64 KiB): W ring, 2 slots x [s(2)][tile(16)][lane(64)] x 16 B;  [64, 80 KiB): G exchange,
+    // 2 slots x [M-tile(4)][s(2)][lane(64)] x 16 B.  The epilogue reuses all of it.
+    __shared__ __attribute__((aligned(16))) u32x4 s_mem[2 * 2048 + 2 * 512];
+    u32x4 *s_b = s_mem, *s_g = s_mem + 2 * 2048;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
     const int j = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
@@ -371,18 +381,19 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
     const int t0 = tt * BG_BT, u0 = ub * BG_BU;
     const int VC = V / 32;
 
-    // this lane's producer row: cell (pt, pu) or none
-    const int pt = t0 + 2 * wave + (j >> 4), pu = u0 + (j & 15);
+    // ---- producer role: cell (pt, pu), vocabulary quarter qd of every chunk
+    const int r16 = lane & 15, qd = lane >> 4;
+    const int pt = t0 + wave, pu = u0 + r16;
     const bool pexists = pt < T && pu < U1;
     const long zrow = (long)a.B * T * U1;  // first zero padding row
     const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : zrow;
     float *lrow = a.logits + pcell * V;
-    u32x4 *grow = (u32x4 *)lrow + 2 * half;  // chunk c: grow[4c], grow[4c+1]  (32 B of bf16)
+    u32x4 *grow = (u32x4 *)lrow + qd;  // chunk c: grow[4c]  (16 B of bf16 at byte 64c + 16qd)
 
     if (t0 >= Tb) {  // workgroup-uniform: no products, but k_dw_bf16 must find zeros here
         if (pexists) {
             const u32x4 z = {0u, 0u, 0u, 0u};
-            for (int c = 0; c < VC; ++c) { grow[4 * c] = z; grow[4 * c + 1] = z; }
+            for (int c = 0; c < VC; ++c) grow[4 * c] = z;
         }
         return;
     }
@@ -391,81 +402,111 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
     const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
     if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
     // rows outside the lattice read the zero padding row (finite) with c1 = -inf -> G = 0
-    const f32x4 *xsrc = (const f32x4 *)(live ? lrow : a.logits + zrow * V) + 4 * half;  // chunk c: xsrc[8c .. 8c+3]
+    const f32x4 *xsrc = (const f32x4 *)(live ? lrow : a.logits + zrow * V) + 2 * qd;  // chunk c: xsrc[8c], xsrc[8c+1]
     const int blank = a.blank;
-    const u32x4 *wp = (const u32x4 *)a.wpack_dh;
+    // fragment image: MFMA s, lane (r, h) holds k = 16h + 8s + 0..7 of the chunk = quarter 2h + s
+    // -> this lane's 16 B go to [M-tile wave>>1][s = qd&1][lane (qd>>1)*32 + 16*(wave&1) + r16]
+    const int gdst = (wave >> 1) * 128 + (qd & 1) * 64 + (qd >> 1) * 32 + 16 * (wave & 1) + r16;
+    const u32x4 *wp = (const u32x4 *)a.wpack_dh + (wave * 4) * 64 + lane;  // this wave's 4 of the chunk's 32 pieces
 
-    f32x16 acc[NT];
+    f32x16 acc[8];
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl)
+    for (int tl = 0; tl < 8; ++tl)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
 
-    f32x4 xr[4][4];  // logits ring, 4 chunks ahead (slot = chunk & 3)
-    BStage<NT> bx, by;
+    auto produce = [&](const f32x4 &x0, const f32x4 &x1, int c, int slot) {
+        float g[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+        for (int e = 0; e < 4; ++e) {
+            g[e] = __builtin_amdgcn_exp2f(fmaf(x0[e], RNNT_LOG2E, cf.c1));
+            g[4 + e] = __builtin_amdgcn_exp2f(fmaf(x1[e], RNNT_LOG2E, cf.c1));
+        }
+        const int vb = 32 * c + 8 * qd;
+        const unsigned dy = (unsigned)(cf.y - vb);
+        if (__any(dy < 8u)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[q][i] = xsrc[8 * (q < VC ? q : VC - 1) + i];
-    bx.load(wp, 0, wave, lane);
-    by.load(wp, 1, wave, lane);
-    bx.store(s_b[0], wave, lane);
-    bx.load(wp, 2, wave, lane);
+            for (int e = 0; e < 8; ++e) g[e] = (dy == (unsigned)e) ? g[e] - cf.se : g[e];
+        }
+        if ((unsigned)(blank - 32 * c) < 32u) {  // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (vb + e == blank) ? g[e] - cf.sb : g[e];
+        }
+        const u32x4 o = {pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3]), pack_bf16(g[4], g[5]), pack_bf16(g[6], g[7])};
+        s_g[slot * 512 + gdst] = o;
+        if (pexists && c < VC && !(a.flags & 256)) grow[4 * c] = o;
+    };
+    auto wload = [&](u32x4 (&w)[4], int c) {
+        const u32x4 *p = wp + (long)(c < VC ? c : VC - 1) * 2048;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = p[i * 64];
+    };
+    auto wstore = [&](const u32x4 (&w)[4], int slot) {
+        u32x4 *p = s_b + slot * 2048 + (wave * 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i * 64] = w[i];
+    };
+    auto xload = [&](f32x4 (&x)[2], int c) {
+        const int cc = c < VC ? c : VC - 1;
+        x[0] = xsrc[8 * cc];
+        x[1] = xsrc[8 * cc + 1];
+    };
+
+    f32x4 xr[4][2];  // logits ring (slot = chunk & 3), 4 chunks ahead of production
+    u32x4 wx[4], wy[4];  // staged W: even / odd chunks
+    xload(xr[0], 0); xload(xr[1], 1); xload(xr[2], 2); xload(xr[3], 3);
+    wload(wx, 0);
+    wload(wy, 1);
+    wstore(wx, 0);
+    wload(wx, 2);
+    produce(xr[0][0], xr[0][1], 0, 0);
+    xload(xr[0], 4);
     lds_barrier();
 
     for (int c0 = 0; c0 < VC; c0 += 4) {  // VC % 4 == 0
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = c0 + q;
-            const int nxt = c + 3 < VC ? c + 3 : VC - 1;
-            if (q & 1) { bx.store(s_b[0], wave, lane); bx.load(wp, nxt, wave, lane); }
-            else       { by.store(s_b[1], wave, lane); by.load(wp, nxt, wave, lane); }
-            // ---- G of chunk c for this lane's 16 vocabulary entries v = 32c + 16*half + e
-            float g[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    g[4 * i + e] = __builtin_amdgcn_exp2f(fmaf(xr[q][i][e], RNNT_LOG2E, cf.c1));
-            const int vb = 32 * c + 16 * half;
-            const unsigned dy = (unsigned)(cf.y - vb);
-            if (__any(dy < 16u)) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (dy == (unsigned)e) g[e] -= cf.se;
-            }
-            if ((unsigned)(blank - 32 * c) < 32u) {  // wave-uniform
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (vb + e == blank) g[e] -= cf.sb;
-            }
-            {
-                const int c4 = c + 4 < VC ? c + 4 : VC - 1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xr[q][i] = xsrc[8 * c4 + i];
-            }
-            u32x4 a0, a1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a0[e] = pack_bf16(g[2 * e], g[2 * e + 1]);
-                a1[e] = pack_bf16(g[8 + 2 * e], g[8 + 2 * e + 1]);
-            }
-            if (pexists && !(a.flags & 256)) { grow[4 * c] = a0; grow[4 * c + 1] = a1; }
+            if (q & 1) { wstore(wx, 0); wload(wx, c + 3); }
+            else       { wstore(wy, 1); wload(wy, c + 3); }
+            // G of chunk c+1 (logits requested 4 chunks ago) into the other exchange slot
+            produce(xr[(q + 1) & 3][0], xr[(q + 1) & 3][1], c + 1, (q + 1) & 1);
+            xload(xr[(q + 1) & 3], c + 5);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk<NT, 5>(acc, a0, a1, s_b[q & 1], lane);
+            {
+                const u32x4 a0 = s_g[(q & 1) * 512 + wm * 128 + lane];
+                const u32x4 a1 = s_g[(q & 1) * 512 + wm * 128 + 64 + lane];
+                // this wave's 8 column tiles of the staged chunk: tiles 8wn .. 8wn+7 of each s
+                const u32x4 *pb = s_b + (q & 1) * 2048 + (8 * wn) * 64 + lane;
+                constexpr int DEPTH = 4;
+                u32x4 bf[DEPTH + 1];
+#pragma unroll
+                for (int i = 0; i < DEPTH; ++i) bf[i] = pb[((i >> 3) * 16 + (i & 7)) * 64];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i + DEPTH < 16) bf[(i + DEPTH) % (DEPTH + 1)] = pb[(((i + DEPTH) >> 3) * 16 + ((i + DEPTH) & 7)) * 64];
+                    acc[i & 7] = mfma_bf16(i < 8 ? a0 : a1, bf[i % (DEPTH + 1)], acc[i & 7]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, DEPTH + 2, 0);
+#pragma unroll
+                for (int i = 0; i < 16 - DEPTH; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
+            }
             lds_barrier();
         }
     }
 
-    // ---- epilogue.  C layout: accumulator register r of tile 4g+q holds row
-    // (r&3) + 8*(r>>2) + 4*half of the wave's 32 rows = (t-row r>>3, u (r&3)+8*((r>>2)&1)+4*half),
-    // column 128g + 4j + q.
+    // ---- epilogue.  Accumulator register r of tile 4g+q (g = 0,1): row (r&3) + 8(r>>2) + 4*half
+    // of M-tile wm = (t-row 2wm + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 256wn + 128g + 4j + q.
     if (a.flags & 8192) return;
-    float *s_red = (float *)s_b;  // [4 waves][64 lanes][33]
+    float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int col0 = 128 * g + 4 * j;
+    for (int g = 0; g < 2; ++g) {
+        const int col0 = 256 * wn + 128 * g + 4 * j;
         const bool colok = col0 < H;
         float psum[8][4];
 #pragma unroll
@@ -474,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
             for (int q = 0; q < 4; ++q) psum[r7][q] = 0.f;
 #pragma unroll
         for (int tl_ = 0; tl_ < 2; ++tl_) {
-            const int t = t0 + 2 * wave + tl_;
+            const int t = t0 + 2 * wm + tl_;
             const bool tok = t < Tb;
             float esum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -499,23 +540,24 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_bf16(Bf16Args a)
                 *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + col0) = o;
             }
         }
-        __syncthreads();  // previous g's readers are done with s_red
+        __syncthreads();  // main loop / previous g done with the LDS being reused
 #pragma unroll
         for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
             for (int q = 0; q < 4; ++q) s_red[(wave * 64 + lane) * 33 + r7 * 4 + q] = psum[r7][q];
         __syncthreads();
-        // thread (wave, lane) sums rows r7 = 2*wave, 2*wave+1 of source lane `lane` over the 4 waves
+        // thread (wm, lane) of column half wn sums rows r7 = 2wm, 2wm+1 of source lane `lane`
+        // over the 4 waves (M-tiles) that share wn
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int r7 = 2 * wave + k;
+            const int r7 = 2 * wm + k;
             const int u = u0 + (r7 & 3) + 8 * (r7 >> 2) + 4 * half;
             if (u < U1 && colok) {
                 f32x4 o;
+                const float *sr = s_red + (wn * 4 * 64 + lane) * 33 + r7 * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    o[q] = (s_red[(0 * 64 + lane) * 33 + r7 * 4 + q] + s_red[(1 * 64 + lane) * 33 + r7 * 4 + q]) +
-                           (s_red[(2 * 64 + lane) * 33 + r7 * 4 + q] + s_red[(3 * 64 + lane) * 33 + r7 * 4 + q]);
+                    o[q] = (sr[q] + sr[64 * 33 + q]) + (sr[2 * 64 * 33 + q] + sr[3 * 64 * 33 + q]);
                 *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + col0) = o;
             }
         }
@@ -528,7 +570,7 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
     // zero padding rows: G of rows k_dw_bf16 walks past the last cell, and the "dead row" source
     (void)hipMemsetAsync(a.logits + cells * a.V, 0, (size_t)(a.rows_alloc - cells) * a.V * 4, st);
     dim3 grid(a.n_ublk, (a.T + BG_BT - 1) / BG_BT, a.B);
-    hipLaunchKernelGGL(k_dhidden_bf16, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dhidden_bf16, grid, dim3(512), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------
