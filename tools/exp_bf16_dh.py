@@ -1,0 +1,22 @@
+"""Experiment: bf16 dHidden stage with G stores / epilogue switched off."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synth
+from rnnt_amd import engine
+B, T, U, H, V = 32, 1000, 200, 512, 1024
+enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
+outs = engine.alloc_fused_outputs(enc, pred, W)
+def run(stage): engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V-1, 1/B, outs=outs, stage=stage, dtype="bf16")
+for s in (0, 1, 2, 3): run(s)
+def timeit(stage, n=3):
+    run(stage); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): run(stage)
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n
+for flags, name in ((0, "normal"), (256, "no G stores"), (8192, "no epilogue"), (8192 + 256, "no stores/epilogue")):
+    engine.lib().rnnt_engine_set_flags(flags)
+    print(f"dhidden {name:20s}: {timeit(4):.2f} ms", flush=True)
+engine.lib().rnnt_engine_set_flags(0)
