@@ -122,6 +122,23 @@ int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3]
                                    void *stream);
 
 /*
+ * Greedy-decode scan (next-step row SURVEY.md 8f-2).  The reference's decode loop, rnnt/model.py:108-125,
+ * evaluates joint.single_forward (rnnt/joint.py:44-55) for one audio frame at a time and syncs on
+ * argmax(...).item() per frame.  This call evaluates frames t0 .. t0+nframes-1 (nframes <= 128) of
+ * one utterance against ONE predictor state and reduces on the device:
+ *   out[0] = first frame whose argmax is not `blank` (t0+nframes if every frame says blank)
+ *   out[1] = that token (blank if none);   out[2+k] = argmax of frame t0+k (first index on ties)
+ *   enc  [T,H] rows enc_stride_t apart, elements enc_stride_h apart (the permuted encoder view
+ *        of rnnt/model.py:102 works), already projected by audio_ln when the model has one;
+ *   pred [H] predictor output (after text_ln when present); W [V,H]; bias [V]; out int32[2+nframes].
+ */
+int rnnt_engine_greedy_scan_workspace_bytes(int nframes, int H, int V, size_t *out);
+int rnnt_engine_greedy_scan(const void *enc, int64_t enc_stride_t, int64_t enc_stride_h,
+                            const void *pred, const void *W, const void *bias, int t0, int nframes,
+                            int H, int V, int blank, int32_t *out, void *workspace, size_t ws_bytes,
+                            void *stream);
+
+/*
  * Diagnostic view of the last fused call's intermediate buffers inside `workspace`
  * (offsets in bytes; valid for the dims given).  Used by tests and bench.py to time or
  * inspect single stages; not needed by training code.

@@ -321,6 +321,40 @@ int rnnt_engine_joint_fwd(const void *enc, const int64_t enc_strides[3], const v
     return launch_status("rnnt_engine_joint_fwd");
 }
 
+int rnnt_engine_greedy_scan_workspace_bytes(int nframes, int H, int V, size_t *out)
+{
+    if (!out) return fail(RNNT_ERR_INVALID_ARG, "null size pointer");
+    if (nframes < 1 || nframes > 128) return fail(RNNT_ERR_INVALID_ARG, "nframes=%d outside [1,128]", nframes);
+    if (int rc = check_dims(1, nframes, 1, H, V, RNNT_DTYPE_F32, true)) return rc;
+    if (H % 8 != 0) return fail(RNNT_ERR_UNSUPPORTED, "greedy scan needs H %% 8 == 0 (H=%d)", H);
+    *out = align_up((size_t)nframes * H * 4) + align_up((size_t)nframes * V * 4);
+    return RNNT_OK;
+}
+
+int rnnt_engine_greedy_scan(const void *enc, int64_t enc_stride_t, int64_t enc_stride_h, const void *pred,
+                            const void *W, const void *bias, int t0, int nframes, int H, int V, int blank,
+                            int32_t *out, void *workspace, size_t ws_bytes, void *stream)
+{
+    size_t need;
+    if (int rc = rnnt_engine_greedy_scan_workspace_bytes(nframes, H, V, &need)) return rc;
+    if (!enc || !pred || !W || !bias || !out || !workspace) return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    if (t0 < 0) return fail(RNNT_ERR_INVALID_ARG, "t0=%d is negative", t0);
+    if (blank < 0 || blank >= V) return fail(RNNT_ERR_INVALID_ARG, "blank=%d outside [0,%d)", blank, V);
+    if (!aligned16(pred) || !aligned16(W) || !aligned16(bias) || ((uintptr_t)workspace & 255))
+        return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
+    if (ws_bytes < need) return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *enc_copy = (float *)ws;
+    float *logits = (float *)(ws + align_up((size_t)nframes * H * 4));
+    const int64_t strides[3] = {0, enc_stride_t, enc_stride_h};
+    const float *encp; long esb, est;
+    resolve_enc((const float *)enc + (int64_t)t0 * enc_stride_t, strides, 1, nframes, H, enc_copy, st, &encp, &esb, &est);
+    launch_scan_logits(encp, est, (const float *)pred, (const float *)W, (const float *)bias, logits, nframes, H, V, st);
+    launch_argmax_scan(logits, nframes, V, blank, t0, out, st);
+    return launch_status("rnnt_engine_greedy_scan");
+}
+
 int rnnt_engine_loss_fwd_bwd(const void *logits, const int32_t *targets, const int32_t *logit_lens,
                              const int32_t *target_lens, int B, int T, int U1, int V, int blank,
                              float clamp, int dtype, float *costs, void *grad_logits,

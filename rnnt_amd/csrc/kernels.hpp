@@ -94,3 +94,8 @@ void launch_bf16_producers(const Bf16Args &a, hipStream_t st);
 void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st);
 void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st);
 void launch_dw_bf16(const Bf16Args &a, hipStream_t st);
+
+// ---- decode.hip
+void launch_scan_logits(const float *enc, long enc_st, const float *pred, const float *W, const float *bias,
+                        float *logits, int K, int H, int V, hipStream_t st);
+void launch_argmax_scan(const float *logits, int K, int V, int blank, int t0, int32_t *out, hipStream_t st);

@@ -37,6 +37,7 @@ EXPORTS = (
     "rnnt_engine_loss_workspace_bytes", "rnnt_engine_joint_fwd_workspace_bytes",
     "rnnt_engine_joint_fwd", "rnnt_engine_loss_fwd_bwd", "rnnt_engine_joint_loss_fwd_bwd",
     "rnnt_engine_workspace_layout", "rnnt_engine_run_stage",
+    "rnnt_engine_greedy_scan_workspace_bytes", "rnnt_engine_greedy_scan",
 )
 
 
@@ -224,3 +225,32 @@ def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, bla
     else:
         _check(lib().rnnt_engine_run_stage(int(stage), *args))
     return outs
+
+
+GREEDY_SCAN_MAX_FRAMES = 128
+
+
+def greedy_scan(enc, pred, W, bias, t0, nframes, blank):
+    """Greedy-decode scan (C ABI rnnt_engine_greedy_scan; reference rnnt/model.py:108-125 inner
+    loop): frames t0 .. t0+nframes-1 of `enc` [T,H] (any strides) against ONE predictor state
+    `pred` [H].  Returns an int32 device tensor [2+nframes]: first non-blank frame (t0+nframes if
+    none), its token, then the argmax of every frame.  No host synchronisation."""
+    dev = _require_cuda(enc, pred, W, bias)
+    if enc.dim() != 2 or pred.dim() != 1 or enc.shape[1] != pred.shape[0] or W.shape[1] != pred.shape[0]:
+        raise RuntimeError("greedy_scan: enc [T,H], pred [H], W [V,H] expected")
+    if enc.dtype != torch.float32 or pred.dtype != torch.float32:
+        raise RuntimeError("greedy_scan: float32 tensors expected")
+    T, H = enc.shape
+    V = W.shape[0]
+    nframes = int(nframes)
+    if t0 < 0 or nframes < 1 or t0 + nframes > T:
+        raise ValueError(f"greedy_scan: frames [{t0}, {t0 + nframes}) outside [0, {T})")
+    n = ctypes.c_size_t(0)
+    _check(lib().rnnt_engine_greedy_scan_workspace_bytes(nframes, H, V, ctypes.byref(n)))
+    ws = workspace(dev, n.value)
+    out = torch.empty(2 + nframes, dtype=torch.int32, device=dev)
+    _check(lib().rnnt_engine_greedy_scan(_p(enc), ctypes.c_int64(enc.stride(0)), ctypes.c_int64(enc.stride(1)),
+                                         _p(pred.contiguous()), _p(W.contiguous()), _p(bias.contiguous()),
+                                         int(t0), nframes, H, V, int(blank), _p(out), _p(ws),
+                                         ctypes.c_size_t(ws.numel()), _stream(dev)))
+    return out

@@ -45,6 +45,17 @@ class JointNetwork(torch.nn.Module):
                                      self.joint_ln.bias, targets, logit_lengths, target_lengths,
                                      blank=blank, reduction=reduction, **kw)
 
+    def greedy_scan(self, audio_frames, text_frame, t0, nframes):
+        """Decode helper (reference rnnt/model.py:108-125): argmax of single_forward for frames
+        t0 .. t0+nframes-1 of `audio_frames` [T,H] (ALREADY projected by audio_ln) against one
+        predictor frame `text_frame` [Ft], reduced on the device to (first non-blank frame, token).
+        Returns the engine's int32 tensor [2+nframes]; the caller syncs once per block."""
+        from . import engine
+        if hasattr(self, "text_ln"):
+            text_frame = self.text_ln(text_frame)
+        return engine.greedy_scan(audio_frames, text_frame, self.joint_ln.weight, self.joint_ln.bias,
+                                  t0, nframes, self.blank_idx)
+
     def single_forward(self, audio_frame, text_frame):
         """One (audio, text) frame pair at a time: greedy decode and export (joint.py:44-55)."""
         audio_frame, text_frame = self._project(audio_frame, text_frame)

@@ -44,7 +44,12 @@ class RNNTModel(torch.nn.Module):
 
     @torch.no_grad()
     def greedy_decode(self, mel_features: torch.Tensor, mel_feature_lens: torch.Tensor,
-                      max_length: int = 200):
+                      max_length: int = 200, scan_frames: int = 32):
+        """Greedy decode with the reference's control flow (rnnt/model.py:95-125): emit the argmax
+        token until blank or 10 symbols per frame, then advance.  The joint + argmax of up to
+        `scan_frames` consecutive frames run on the engine per call (JointNetwork.greedy_scan), so
+        the host syncs once per emitted token / all-blank block instead of once per frame;
+        scan_frames=0 keeps the per-frame single_forward loop."""
         assert mel_features.shape[0] == 1, "Greedy decoding only works with a batch size of 1"
         stateful = self._predictor_is_stateful()
         audio = self.encoder(mel_features).permute(0, 2, 1)
@@ -61,15 +66,36 @@ class RNNTModel(torch.nn.Module):
             return self.predictor(ids_t), None
 
         feats, state = run_predictor(tokens)
+        T = audio.shape[1]
+        use_scan = scan_frames > 0 and audio.is_cuda
+        if use_scan:
+            frames = audio[0]  # [T,C] view of the encoder output; projected once for all frames
+            if hasattr(self.joint, "audio_ln"):
+                frames = self.joint.audio_ln(frames)
+            frames = frames.float()
         t, emitted = 0, 0
-        while t < audio.shape[1] and len(tokens) < max_length:
-            logits = self.joint.single_forward(audio[:, t, :], feats[:, -1, :])
-            tok = int(logits.argmax(dim=-1))
-            if tok == self.joint.blank_idx or emitted >= 10:
+        while t < T and len(tokens) < max_length:
+            if emitted >= 10:  # reference: max_outputs_per_step reached -> next frame, whatever the token
                 t += 1
                 emitted = 0
+                continue
+            if use_scan:
+                n = min(scan_frames, T - t)
+                res = self.joint.greedy_scan(frames, feats[0, -1, :].float(), t, n)
+                t_hit, tok = res[:2].tolist()  # the one sync of this block
+                if t_hit > t:
+                    emitted = 0
+                t = t_hit
+                if tok == self.joint.blank_idx:  # every scanned frame said blank
+                    continue
             else:
-                tokens.append(tok)
-                feats, state = run_predictor([tok], state) if stateful else run_predictor(tokens)
-                emitted += 1
+                logits = self.joint.single_forward(audio[:, t, :], feats[:, -1, :])
+                tok = int(logits.argmax(dim=-1))
+                if tok == self.joint.blank_idx:
+                    t += 1
+                    emitted = 0
+                    continue
+            tokens.append(tok)
+            feats, state = run_predictor([tok], state) if stateful else run_predictor(tokens)
+            emitted += 1
         return tokens[1:]

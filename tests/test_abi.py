@@ -97,3 +97,16 @@ def test_bf16_dtype_queries_and_validation(lib):
     assert engine.dtype_code(torch.bfloat16) == 1
     with pytest.raises(ValueError):
         engine.dtype_code("fp8")
+
+
+def test_greedy_scan_entry_validation(lib):
+    lib.rnnt_engine_last_error.restype = ctypes.c_char_p
+    n = ctypes.c_size_t(0)
+    assert lib.rnnt_engine_greedy_scan_workspace_bytes(32, 512, 1024, ctypes.byref(n)) == 0
+    assert n.value >= 32 * 1024 * 4 + 32 * 512 * 4
+    assert lib.rnnt_engine_greedy_scan_workspace_bytes(129, 512, 1024, ctypes.byref(n)) == -1
+    assert lib.rnnt_engine_greedy_scan_workspace_bytes(8, 510, 1024, ctypes.byref(n)) == -2
+    assert lib.rnnt_engine_greedy_scan_workspace_bytes(8, 508, 1024, ctypes.byref(n)) == -2  # H % 8
+    rc = lib.rnnt_engine_greedy_scan(None, ctypes.c_int64(512), ctypes.c_int64(1), None, None, None, 0, 8, 512,
+                                     1024, 1023, None, None, ctypes.c_size_t(0), None)
+    assert rc == -1 and b"null" in lib.rnnt_engine_last_error()

@@ -321,3 +321,67 @@ def test_bf16_rejects_unsupported_dims(amd):
     d = make_inputs(2, 5, 2, 64, 128, seed=3)
     with pytest.raises(RuntimeError, match="RNNT_DTYPE_BF16"):
         _run_fused(amd, d, dtype="bf16")
+
+
+# ---- greedy-decode scan (reference rnnt/model.py:108-125, joint.py:44-55)
+@pytest.mark.parametrize("T,H,V,n,t0", [(50, 64, 40, 32, 7), (9, 512, 1024, 9, 0), (200, 128, 260, 128, 72)])
+def test_greedy_scan_vs_torch(amd, T, H, V, n, t0):
+    torch.manual_seed(T + V)
+    enc_ct = torch.randn(H, T, device="cuda")         # encoder layout (C,T): the scan gets the permuted view
+    enc = enc_ct.permute(1, 0)
+    pred = torch.randn(H, device="cuda")
+    W = torch.randn(V, H, device="cuda") / H ** 0.5
+    bias = torch.randn(V, device="cuda") * 0.1
+    blank = V - 1
+    bias[blank] += 1.5  # make blank frequent, as in a trained model
+    out = amd.engine.greedy_scan(enc, pred, W, bias, t0, n, blank).cpu().numpy()
+    logits = torch.tanh(enc[t0:t0 + n].double() + pred.double()) @ W.double().T + bias.double()
+    ref = logits.argmax(dim=-1).cpu().numpy()
+    # ties/near-ties between fp32 MFMA and fp64: compare where the top-2 margin is clear
+    top2 = logits.topk(2, dim=-1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 1e-4).cpu().numpy()
+    assert clear.mean() > 0.9
+    assert (out[2:][clear] == ref[clear]).all()
+    assert clear.all(), "seeded inputs are expected to have clear margins"
+    nb = np.nonzero(ref != blank)[0]
+    if len(nb):
+        assert out[0] == t0 + nb[0] and out[1] == ref[nb[0]]
+    else:
+        assert out[0] == t0 + n and out[1] == blank
+
+
+def test_greedy_decode_scan_matches_per_frame_loop(amd):
+    """RNNTModel.greedy_decode with the device-side scan == the reference's per-frame loop
+    (rnnt/model.py:95-125: emit until blank or 10 symbols per frame)."""
+    torch.manual_seed(3)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv1d(10, 24, 3, stride=2, padding=1)
+
+        def forward(self, x):
+            return self.c(x)
+
+        def calc_output_lens(self, lens):
+            return (lens + 1) // 2
+
+    class Pred(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.e = torch.nn.Embedding(16, 20)
+
+        def forward(self, ids):
+            return self.e(ids)
+
+    for fa, ft, hid in ((-1, -1, 24), (24, 20, 32)):  # without / with audio_ln + text_ln
+        pred_mod = Pred() if ft > 0 else torch.nn.Embedding(16, 24)
+        model = amd.RNNTModel(pred_mod, Enc(), amd.JointNetwork(fa, ft, hid, 16)).cuda()
+        with torch.no_grad():
+            model.joint.joint_ln.bias[15] += 1.0
+        mel = torch.randn(1, 10, 120, device="cuda")
+        lens = torch.tensor([120], device="cuda")
+        a = model.greedy_decode(mel, lens, max_length=80, scan_frames=16)
+        b = model.greedy_decode(mel, lens, max_length=80, scan_frames=0)
+        assert a == b and 0 < len(a) <= 79
+        assert model.greedy_decode(mel, lens, max_length=80, scan_frames=128) == b
