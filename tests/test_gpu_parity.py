@@ -238,10 +238,10 @@ def test_fused_path_is_bitwise_reproducible(amd):
 
 
 # ---------------------------------------------------------------- full-size properties
-def _full(amd, B, T, U, H, V, seed):
+def _full(amd, B, T, U, H, V, seed, dtype="fp32"):
     d = make_inputs(B, T, U, H, V, seed, ragged=False)
     d["W"] = np.zeros_like(d["W"])  # logits == bias in every cell: closed-form loss
-    r = _run_fused(amd, d)
+    r = _run_fused(amd, d, dtype=dtype)
     bias = d["bias"].astype(np.float64)
     lp = bias - np.log(np.exp(bias).sum())
     for b in range(B):
@@ -385,3 +385,30 @@ def test_greedy_decode_scan_matches_per_frame_loop(amd):
         b = model.greedy_decode(mel, lens, max_length=80, scan_frames=0)
         assert a == b and 0 < len(a) <= 79
         assert model.greedy_decode(mel, lens, max_length=80, scan_frames=128) == b
+
+
+def _bf16_vs_fp32_fullsize(amd, B, T, U, H, V, seed):
+    """Full-size ragged inputs through both routes: every bf16 kernel at BASELINE sizes (row
+    offsets beyond 2^31 bytes, all tiles / passes / splits), held to bf16's error of the fp32 route."""
+    d = make_inputs(B, T, U, H, V, seed)
+    amd.engine.release_workspaces()
+    ref = _run_fused(amd, d)
+    amd.engine.release_workspaces()
+    r = _run_fused(amd, d, dtype="bf16")
+    amd.engine.release_workspaces()
+    assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL_EXACT)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL_EXACT)
+
+
+def test_fullsize_config2_bf16_vs_fp32(amd):
+    """BASELINE config 3's per-step arithmetic at config 2's size (B=32,T=1000,U=200,H=512,V=1024)."""
+    _bf16_vs_fp32_fullsize(amd, 32, 1000, 200, 512, 1024, seed=32)
+    _full(amd, 32, 1000, 200, 512, 1024, seed=2, dtype="bf16")
+    amd.engine.release_workspaces()
+
+
+def test_fullsize_config5_bf16_vs_fp32(amd):
+    """Large vocabulary (B=16,T=800,U=150,H=512,V=16384) on the bf16 route: 64 forward passes, 512
+    k chunks per dHidden tile, 64 dW column tiles."""
+    _bf16_vs_fp32_fullsize(amd, 16, 800, 150, 512, 16384, seed=35)
