@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from tests.helpers import (BF16_GRAD_RTOL, BF16_GRAD_RTOL_EXACT, BF16_LOSS_RTOL,
-                           BF16_LOSS_RTOL_EXACT, assert_close_grad, assert_close_loss,
+                           BF16_LOSS_RTOL_EXACT, GRAD_RTOL, LOSS_RTOL, assert_close_grad, assert_close_loss,
                            lgamma_paths_cost, make_inputs, oracle_fused, oracle_fused_bf16)
 
 pytestmark = pytest.mark.gpu
@@ -158,6 +158,30 @@ def test_fused_golden(amd, golden_dir, name):
     assert_close_grad("grad_text", t.grad.cpu().numpy(), z["grad_text"])
     for k, p in m.named_parameters():
         assert_close_grad(k, p.grad.cpu().numpy(), z["grad__" + k.replace(".", "__")])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_golden_inputs_from_reference_modules(amd, golden_dir, dtype):
+    """The joint's inputs come from the reference's own AudioEncoder / ConvPredictor (fixture
+    e2e_refmodules: call sequence of rnnt/model.py:20-29); the encoder output is handed over as
+    the permuted, non-contiguous (N,C,L)->(N,L,C) view exactly as model.py:28 does."""
+    z = np.load(os.path.join(golden_dir, "e2e_refmodules.npz"))
+    m = amd.JointNetwork(*[int(x) for x in z["ctor"]]).cuda()
+    m.load_state_dict(_sd(z))
+    enc_ncl = torch.from_numpy(z["enc_ncl"]).cuda().requires_grad_(True)
+    t = torch.from_numpy(z["text"]).cuda().requires_grad_(True)
+    a = enc_ncl.permute(0, 2, 1)
+    assert not a.is_contiguous()
+    loss = m.fused_loss(a, t, torch.from_numpy(z["targets"]).cuda(),
+                        torch.from_numpy(z["logit_lens"]).cuda(),
+                        torch.from_numpy(z["target_lens"]).cuda(), dtype=dtype)
+    loss.backward()
+    lt, gt = (LOSS_RTOL, GRAD_RTOL) if dtype == "fp32" else (BF16_LOSS_RTOL_EXACT, BF16_GRAD_RTOL_EXACT)
+    assert_close_loss("loss", loss.item(), float(z["loss"]), rtol=lt)
+    assert_close_grad("grad_audio", enc_ncl.grad.permute(0, 2, 1).cpu().numpy(), z["grad_audio"], rtol=gt)
+    assert_close_grad("grad_text", t.grad.cpu().numpy(), z["grad_text"], rtol=gt)
+    for k, p in m.named_parameters():
+        assert_close_grad(k, p.grad.cpu().numpy(), z["grad__" + k.replace(".", "__")], rtol=gt)
 
 
 def test_model_forward_matches_unfused(amd):

@@ -62,6 +62,22 @@ def test_oracle_e2e_matches_golden(golden_dir, name):
                                    z["grad_audio"], atol=1e-11)
 
 
+def test_oracle_e2e_matches_golden_from_reference_modules(golden_dir):
+    """Inputs produced by the reference's own AudioEncoder / ConvPredictor (call sequence of
+    rnnt/model.py:20-29); expected values from the reference JointNetwork in fp64."""
+    z = np.load(os.path.join(golden_dir, "e2e_refmodules.npz"))
+    sd = _sd(z)
+    audio = np.ascontiguousarray(z["enc_ncl"].transpose(0, 2, 1)).astype(np.float64)  # model.py:28
+    r = cpu_oracle.joint_loss_fwd_bwd(audio, z["text"].astype(np.float64), sd["joint_ln.weight"],
+                                      sd["joint_ln.bias"], z["targets"], z["logit_lens"], z["target_lens"])
+    np.testing.assert_allclose(r["loss"], z["loss"], rtol=1e-12)
+    np.testing.assert_allclose(r["costs"], z["costs"], rtol=1e-12)
+    np.testing.assert_allclose(r["grad_enc"], z["grad_audio"], atol=1e-11)
+    np.testing.assert_allclose(r["grad_pred"], z["grad_text"], atol=1e-11)
+    np.testing.assert_allclose(r["grad_W"], z["grad__joint_ln__weight"], atol=1e-11)
+    np.testing.assert_allclose(r["grad_bias"], z["grad__joint_ln__bias"], atol=1e-11)
+
+
 @pytest.mark.parametrize("T,U,V,seed", [(1, 0, 4, 0), (1, 3, 5, 1), (4, 0, 5, 2), (4, 3, 5, 3),
                                         (5, 4, 3, 4), (6, 2, 8, 5)])
 def test_oracle_loss_vs_bruteforce(T, U, V, seed):
