@@ -315,16 +315,20 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         return *(const f32x4 *)(xsrc + xstep * (c8 < VK ? c8 : VK - 1));
     };
 
-    f32x4 xr[4];           // raw logits of chunks c+2 .. c+5 (ring, slot = chunk & 3)
+    f32x4 xr[4];           // raw logits of chunks c+3 .. c+6 (ring, slot = chunk & 3)
     f32x4 wf[2][4][2];     // W fragments of chunks c, c+1 (slot = chunk & 1)
     xr[0] = xload(0); xr[1] = xload(1); xr[2] = xload(2); xr[3] = xload(3);
     wload(wf[0], 0);
     wload(wf[1], 1);
-    // G is produced TWO chunks ahead of its MFMAs (4-slot LDS exchange, slot = chunk & 3): the
-    // fragments of chunk c+1 are already published while chunk c is multiplied, so they are read
-    // inside chunk c's MFMA stream and no LDS latency stands at the top of a chunk.
+    // G is produced THREE chunks ahead of its MFMAs (4-slot LDS exchange, slot = chunk & 3) and
+    // read one chunk ahead, inside the previous chunk's MFMA stream: no LDS latency stands at the
+    // top of a chunk, and the workgroup only needs a barrier every SECOND chunk (after the even
+    // ones): between the write of chunk k's fragments (during chunk k-3) and their read (during
+    // chunk k-1), and between the last read of a slot (chunk k-5) and its rewrite (chunk k-3),
+    // one of the two chunk ends in between is a barrier.  Half the barriers = half the time the
+    // four waves spend waiting for the slowest of them.
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         const f32x4 gk = gen(xr[k], k);
         *(f32x4 *)(smem + k * 1024 + wave * 256 + 4 * lane) = gk;
         if (pexists) *(f32x4 *)(lptr + 8 * k) = gk;
@@ -352,12 +356,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 const float gv = mt == 0 ? a0[s_] : a1[s_];
                 acc[mt][g * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, cur[s_][g][q], acc[mt][g * 4 + q], 0, 0, 0);
             };
-            // ---- k-step 0, with the production of chunk c8+2 (logits requested 4 chunks ago)
-            const bool produce = c8 + 2 < VK;  // workgroup-uniform
-            const int cn = c8 + 2, vbn = 8 * cn + 4 * half;
+            // ---- k-step 0, with the production of chunk c8+3 (logits requested 4 chunks ago)
+            const bool produce = c8 + 3 < VK;  // workgroup-uniform
+            const int cn = c8 + 3, vbn = 8 * cn + 4 * half;
             f32x4 gn;
             {
-                const f32x4 &x = xr[(j + 2) & 3];
+                const f32x4 &x = xr[(j + 3) & 3];
                 mf(0, 0); cur[1][0] = wf[j & 1][1][0]; PIN();
                 mf(0, 1); cur[1][1] = wf[j & 1][1][1]; PIN();
                 mf(0, 2);
@@ -391,12 +395,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 PIN();
                 mf(0, 7);
                 if (produce) {
-                    *(f32x4 *)(smem + ((j + 2) & 3) * 1024 + wave * 256 + 4 * lane) = gn;
+                    *(f32x4 *)(smem + ((j + 3) & 3) * 1024 + wave * 256 + 4 * lane) = gn;
                     if (pexists && !xp_nost) *(f32x4 *)(lptr + 8 * cn) = gn;
                 }
                 PIN();
                 mf(0, 8);
-                xr[(j + 2) & 3] = xload(c8 + 6);
+                xr[(j + 3) & 3] = xload(c8 + 7);
                 PIN();
 #pragma unroll
                 for (int m = 9; m < 16; ++m) mf(0, m);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             mf(1, 2); cur[3][0] = wf[j & 1][3][0]; PIN();
             mf(1, 3); cur[3][1] = wf[j & 1][3][1]; PIN();
             mf(1, 4);
-            // fragments of chunk c8+1 (written during chunk c8-1, published by its barrier)
+            // fragments of chunk c8+1 (written during chunk c8-2; a barrier has passed since)
             const f32x4 an0 = *(const f32x4 *)(smem + ((j + 1) & 3) * 1024 + (2 * wm) * 256 + 4 * lane);
             const f32x4 an1 = *(const f32x4 *)(smem + ((j + 1) & 3) * 1024 + (2 * wm + 1) * 256 + 4 * lane);
             PIN();
@@ -426,8 +430,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             PIN();
             // publish chunk c8+1's fragments / free chunk c8's buffer.  Raw barrier: a
             // __syncthreads() would add s_waitcnt vmcnt(0) and drain the logits / W prefetch.
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(j & 1)) {  // after even chunks (chunk 0's fragments were read in the prologue)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             PIN();
             a0 = an0;
             a1 = an1;
