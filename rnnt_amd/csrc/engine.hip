@@ -182,7 +182,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
-    g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags & ~16;
+    g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags & ~16; g.debug = g_debug;
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;
         h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;

@@ -231,6 +231,20 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
 // accumulators; W fragments straight L2 -> VGPR one chunk ahead; logits three chunks ahead.
 // Tiles with t0 >= T_b (ragged batches) only zero their G rows.  grid (n_ublk, ceil(T/8), B).
 #define DG_BT 8
+#ifdef RNNT_STAMPS
+// Diagnostic build only (make EXTRA=-DRNNT_STAMPS): s_memtime stamps of every 16th workgroup.
+#define GSTAMP(slot)                                                                          \
+    do {                                                                                      \
+        const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;  \
+        if (a.debug && threadIdx.x == 0 && (wg_ & 15) == 0 && wg_ < 16 * 4096) {              \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            a.debug[(wg_ >> 4) * 8 + (slot)] = t_;                                            \
+        }                                                                                     \
+    } while (0)
+#else
+#define GSTAMP(slot) do {} while (0)
+#endif
 __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[4 * 4 * 256 + 2 * 64 * 65];  // 4-slot G exchange + epilogue
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         }
         return;
     }
+    GSTAMP(0);
 
     CellCoef cf = a.coef[pexists ? pcell : 0];
     const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
@@ -335,6 +350,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         xr[k] = xload(4 + k);
     }
     __syncthreads();
+    GSTAMP(1);
     f32x4 a0 = *(const f32x4 *)(smem + (2 * wm) * 256 + 4 * lane);       // fragments of chunk 0
     f32x4 a1 = *(const f32x4 *)(smem + (2 * wm + 1) * 256 + 4 * lane);
     // One MFMA of the chunk: number m (0..15) of k-step s_.  PIN() keeps what the source puts
@@ -419,12 +435,20 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
             for (int m = 5; m < 16; ++m) mf(1, m);
             PIN();
-            // ---- k-steps 2, 3; the ring slot is copied out: refill it with chunk c8+2
-            mf(2, 0);
-            wload(wf[j & 1], c8 + 2);
-            PIN();
+            // ---- k-steps 2, 3; the ring slot is copied out: refill it with chunk c8+2, ONE load
+            // per MFMA gap (a gap hides ~56 issue cycles; 8 loads + their address arithmetic in one
+            // gap overflowed it)
+            {
+                const int cc = c8 + 2 < VK ? c8 + 2 : VK - 1;
 #pragma unroll
-            for (int m = 1; m < 16; ++m) mf(2, m);
+                for (int m = 0; m < 8; ++m) {
+                    mf(2, m);
+                    wf[j & 1][m >> 1][m & 1] = *(const f32x4 *)(wptr[m & 1] + (long)(8 * cc + (m >> 1)) * H);
+                    PIN();
+                }
+            }
+#pragma unroll
+            for (int m = 8; m < 16; ++m) mf(2, m);
 #pragma unroll
             for (int m = 0; m < 16; ++m) mf(3, m);
             PIN();
@@ -440,6 +464,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         }
     }
 #undef PIN
+    GSTAMP(2);
 
     // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
     if (a.flags & 8192) return;  // experiment switch
@@ -510,6 +535,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             }
         }
     }
+    GSTAMP(3);
 }
 
 bool dhidden_gen_ok(int H, int V) { return H <= 512 && (V % 32) == 0; }

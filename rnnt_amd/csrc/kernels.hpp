@@ -59,6 +59,7 @@ struct JointBwdArgs {
     unsigned *counter;  // 8 x 64 zeroed bytes: per-XCD work-item counters of the persistent kernels
     int n_cu;           // compute units (grid size of the persistent kernels)
     int flags;          // bit 4 (16): G is produced by k_dhidden_gen; others: experiment switches
+    unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
 };
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);

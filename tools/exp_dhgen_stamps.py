@@ -1,0 +1,24 @@
+"""Diagnostic (RNNT_STAMPS build only): phase stamps of k_dhidden_gen workgroups."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bench import synth
+from rnnt_amd import engine
+B, T, U, H, V = 32, 1000, 200, 512, 1024
+enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
+outs = engine.alloc_fused_outputs(enc, pred, W)
+def run(stage): engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V-1, 1/B, outs=outs, stage=stage)
+for s in (0, 1, 2, 3, 4): run(s)
+torch.cuda.synchronize()
+dbg = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+engine.lib().rnnt_engine_set_debug(ctypes.c_void_p(dbg.data_ptr()))
+run(4); torch.cuda.synchronize()
+engine.lib().rnnt_engine_set_debug(ctypes.c_void_p(0))
+d = dbg.cpu().numpy().reshape(4096, 8).astype(np.float64)
+d = d[d[:, 0] > 0]
+print("workgroups stamped:", len(d))
+for k, n in enumerate(["prologue", "main loop (128 chunks)", "epilogue"]):
+    dt = d[:, k + 1] - d[:, k]
+    print(f"{n:24s} median {np.median(dt):9.0f}  p10 {np.percentile(dt, 10):9.0f}  p90 {np.percentile(dt, 90):9.0f} cycles")
+print("per chunk:", np.median(d[:, 2] - d[:, 1]) / 128, " (64 MFMAs = 4096)")
+print("lifetime:", np.median(d[:, 3] - d[:, 0]))
