@@ -284,6 +284,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     // columns beyond H read column 0: they feed accumulators that are never stored
     const float *wptr[2] = {a.W + (long)(4 * half) * H + (colok[0] ? colg[0] : 0),
                             a.W + (long)(4 * half) * H + (colok[1] ? colg[1] : 0)};
+    const unsigned wrow_bytes = (unsigned)H * 4u;
+    // W as a raw buffer (V*H*4 bytes < 4 GiB is checked by the engine)
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, (int)((unsigned)V * wrow_bytes), 0x00020000);
+    const unsigned woff[2] = {(unsigned)(((4 * half) * H + (colok[0] ? colg[0] : 0)) * 4),
+                              (unsigned)(((4 * half) * H + (colok[1] ? colg[1] : 0)) * 4)};
 
     f32x16 acc[2][8];
 #pragma unroll
@@ -439,11 +445,16 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
             // per MFMA gap (a gap hides ~56 issue cycles; 8 loads + their address arithmetic in one
             // gap overflowed it)
             {
+                // buffer loads: descriptor + uniform row offset in SGPRs, 32-bit per-lane offset —
+                // no vector address arithmetic (every instruction between MFMAs costs ~6
+                // matrix-pipe cycles)
                 const int cc = c8 + 2 < VK ? c8 + 2 : VK - 1;
+                const unsigned rowb = (unsigned)(8 * cc) * wrow_bytes;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     mf(2, m);
-                    wf[j & 1][m >> 1][m & 1] = *(const f32x4 *)(wptr[m & 1] + (long)(8 * cc + (m >> 1)) * H);
+                    wf[j & 1][m >> 1][m & 1] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[m & 1], rowb + (m >> 1) * wrow_bytes, 0));
                     PIN();
                 }
             }
