@@ -231,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
 // accumulators; W fragments straight L2 -> VGPR one chunk ahead; logits three chunks ahead.
 // Tiles with t0 >= T_b (ragged batches) only zero their G rows.  grid (n_ublk, ceil(T/8), B).
 #define DG_BT 8
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #ifdef RNNT_STAMPS
 // Diagnostic build only (make EXTRA=-DRNNT_STAMPS): s_memtime stamps of every 16th workgroup.
 #define GSTAMP(slot)                                                                          \
@@ -288,6 +289,18 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     // W as a raw buffer (V*H*4 bytes < 4 GiB is checked by the engine)
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void *)a.W, 0, (int)((unsigned)V * wrow_bytes), 0x00020000);
+    // The tile's logits rows as a raw buffer (8 t x 16 u cells span < (7 U1 + 16) rows): the
+    // per-lane row offset is a 32-bit VGPR, the chunk offset a scalar, and lanes whose row is
+    // outside the lattice point past the end — their loads return 0 (with c1 = -inf: G = 0) and
+    // their stores are dropped, so neither needs a branch or an exec mask.
+    const long cell0 = ((long)b * T + t0) * U1 + u0;
+    const long rows_left = a.rows_pad + 16 - cell0;  // rows of the allocation from cell0 on
+    const long span_rows = (long)(DG_BT - 1) * U1 + DH_BU < rows_left ? (long)(DG_BT - 1) * U1 + DH_BU : rows_left;
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.logits + cell0 * V), 0, (int)(span_rows * V * 4), 0x00020000);
+    const unsigned lane_row_off = (unsigned)((((prow >> 4) * U1 + (prow & 15)) * (long)V + 4 * half) * 4);
+    const unsigned xvoff = live ? lane_row_off : 0xfffffff0u;    // loads: rows of the lattice only
+    const unsigned svoff = pexists ? lane_row_off : 0xfffffff0u;  // stores: every existing cell
     const unsigned woff[2] = {(unsigned)(((4 * half) * H + (colok[0] ? colg[0] : 0)) * 4),
                               (unsigned)(((4 * half) * H + (colok[1] ? colg[1] : 0)) * 4)};
 
@@ -303,8 +316,6 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     // lattice read the zero padding row with c1 = -inf (exp2 -> 0): no per-element select.  The
     // two fixups touch one element of one chunk per row, so they sit behind wave-uniform tests.
     if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
-    const float *xsrc = live ? lptr : a.logits + (long)a.B * T * U1 * V + 4 * half;
-    const long xstep = live ? 8 : 0;  // the zero row is only 1 row long: re-read its start
     auto gen = [&](const f32x4 &x, int c8) {
         f32x4 g;
         const int vb = 8 * c8 + 4 * half;
@@ -330,10 +341,11 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
             for (int g = 0; g < 2; ++g) w[s_][g] = *(const f32x4 *)(wptr[g] + (long)(8 * cc + s_) * H);
     };
-    const bool xp_nold = (a.flags & 4096) != 0, xp_nost = (a.flags & 256) != 0;  // experiment switches
     auto xload = [&](int c8) {
-        if (xp_nold) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return *(const f32x4 *)(xsrc + xstep * (c8 < VK ? c8 : VK - 1));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrsrc, xvoff, 32 * (c8 < VK ? c8 : VK - 1), 0));
+    };
+    auto gstore = [&](const f32x4 &g, int c8) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), lrsrc, svoff, 32 * c8, 0);
     };
 
     f32x4 xr[4];           // raw logits of chunks c+3 .. c+6 (ring, slot = chunk & 3)
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     for (int k = 0; k < 3; ++k) {
         const f32x4 gk = gen(xr[k], k);
         *(f32x4 *)(smem + k * 1024 + wave * 256 + 4 * lane) = gk;
-        if (pexists) *(f32x4 *)(lptr + 8 * k) = gk;
+        gstore(gk, k);
         xr[k] = xload(4 + k);
     }
     __syncthreads();
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     // ring, LDS and memory traffic) rides in those gaps instead of standing in front of the 64
     // MFMAs (where it cost ~450 of every ~4800 cycles).
 #define PIN() __builtin_amdgcn_sched_barrier(0)
+    const int blank_chunk = a.blank >> 3;
     for (int c0 = 0; c0 < VK; c0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 }
                 PIN();
                 mf(0, 6);
-                if (8 * cn <= a.blank && a.blank < 8 * cn + 8) {
+                if (cn == blank_chunk) {  // wave-uniform, one chunk in V/8
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (vbn + e == a.blank) gn[e] -= cf.sb;
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 mf(0, 7);
                 if (produce) {
                     *(f32x4 *)(smem + ((j + 3) & 3) * 1024 + wave * 256 + 4 * lane) = gn;
-                    if (pexists && !xp_nost) *(f32x4 *)(lptr + 8 * cn) = gn;
+                    gstore(gn, cn);
                 }
                 PIN();
                 mf(0, 8);
