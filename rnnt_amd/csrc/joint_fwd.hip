@@ -129,43 +129,48 @@ __device__ __forceinline__ void vm_wait(f32x4 &e, f32x4 &p)
 //    the next chunk retires them and the 2-chunk-old DMA but leaves the newest DMA in flight;
 //  * tanh for chunk c+1 is computed one element per MFMA group while chunk c's MFMAs issue;
 //  * one s_barrier per chunk publishes the ring slot and keeps the SIMD partners in step.
-// Chunk order is rotated per workgroup (`rot`; the k-order of a dot product is free) so the
-// CUs do not all walk the same 16 KB of wpack at once.  W is zero-padded in wpack, tanh of any
-// finite input is finite, and address clamps keep every load in bounds, so no load in the
-// loop is conditional.
+// (A per-workgroup rotation of the chunk order, meant to spread the CUs over wpack, measured
+// no difference and was dropped with its wrap-around arithmetic.)  W is zero-padded in wpack,
+// tanh of any finite input is finite, and address clamps keep every load in bounds, so no load
+// in the loop is conditional.
 template <bool USE_HID>  // true: erow points at the precomputed hidden row (no tanh, no pred)
 __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *prow,
                                              const f32x4 *wpass, int gvalid, int HK,
-                                             long wstride, int H, int half, int rot, int wave,
+                                             long wstride, int H, int half, int wave,
                                              int lane, int wn, f32x4 *ldsb, f32x16 (&acc)[8])
 {
+    // Chunks run in order 0 .. HK-1; fetches that would run past the last chunk re-read it
+    // (clamped, never used).  Every instruction issued between MFMAs costs ~6 matrix-pipe
+    // cycles (measured on k_dhidden_gen), so the per-chunk bookkeeping is kept to scalar adds:
+    // a running uniform DMA source, scalar chunk counters, ring slots by masking.
     // H % 8 == 4: in the last chunk lanes 32-63 would read k >= H; step them back 4 floats
     // (their B values are zero in wpack, so whatever finite A they form contributes 0)
     const int back = (((H & 7) != 0) && half == 1) ? 4 : 0;
     const int last = HK - 1;
-    auto nextc = [&](int cc) { return cc + 1 >= HK ? 0 : cc + 1; };
-    auto aoff = [&](int cc) { return 8 * cc - (cc == last ? back : 0); };
+    const int a_last = 8 * last - back;  // per-lane offset of the last chunk's A slice
     // this wave's share of a chunk's DMA: float4 [wave*128, +128) of the 1024; column groups
     // beyond the last valid one of a partial pass re-read group 0 (their tiles are discarded)
     const int dgrp = wave >> 1;
-    const int dsrc = (dgrp < gvalid ? wave * 128 : (wave & 1) * 128) + lane;
-    auto dma = [&](int cc, int slot) {
-        const f32x4 *src = wpass + (long)cc * wstride + dsrc;
+    const unsigned dlane = (unsigned)(((dgrp < gvalid ? wave * 128 : (wave & 1) * 128) + lane) * 16);  // bytes
+    auto dma = [&](const char *chunk_base, int slot) {  // chunk_base: uniform
+        const char *src = chunk_base + dlane;
         f32x4 *dst = ldsb + slot * FWD_BCHUNK + wave * 128;  // wave-uniform (goes to M0)
-        __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(src + 64, (lds_void_ptr)(dst + 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void *)src, (lds_void_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void *)(src + 1024), (lds_void_ptr)(dst + 64), 16, 0, 0);
     };
     const int roff = wn * 512 + lane;  // this wave's first fragment inside a staged chunk
+    const long wstride_b = wstride * 16;
+    const char *wnext = (const char *)wpass;  // chunk the next DMA fetches
 
     f32x4 w[8];
     float a_cur[4], a_nxt[4];
-    int cc = rot;              // chunk of step 0
-    int c1 = nextc(cc), c2 = nextc(c1);
-    dma(cc, 0);
-    dma(c1, 1);
+    dma(wnext, 0);
+    if (HK > 1) wnext += wstride_b;
+    dma(wnext, 1);
+    if (HK > 2) wnext += wstride_b;
     f32x4 e = {0.f, 0.f, 0.f, 0.f}, p = {0.f, 0.f, 0.f, 0.f};
-    asm_load16(e, erow + aoff(cc));
-    if (!USE_HID) asm_load16(p, prow + aoff(cc));
+    asm_load16(e, erow + (last == 0 ? a_last : 0));
+    if (!USE_HID) asm_load16(p, prow + (last == 0 ? a_last : 0));
     vm_wait<0>(e, p);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -174,22 +179,23 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
 #pragma unroll
     for (int s = 0; s < 4; ++s) a_cur[s] = USE_HID ? e[s] : fast_tanh(e[s] + p[s]);
     __builtin_amdgcn_sched_barrier(0);
-    asm_load16(e, erow + aoff(c1));
-    if (!USE_HID) asm_load16(p, prow + aoff(c1));
+    {
+        const int o1 = last <= 1 ? a_last : 8;
+        asm_load16(e, erow + o1);
+        if (!USE_HID) asm_load16(p, prow + o1);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    dma(c2, 2);
+    dma(wnext, 2);
+    if (HK > 3) wnext += wstride_b;
     __builtin_amdgcn_sched_barrier(0);
-    int cdma = nextc(c2);  // chunk the next DMA fetches (step c8+3)
-    int ca = c2;           // chunk whose raw A is fetched next (step c8+2)
-    int slot_rd = 1, slot_wr = 3;
     for (int c8 = 0; c8 < HK; ++c8) {
         // retire this wave's A slices and its share of the DMA issued two chunks ago (step
         // c8+1's B); the newest DMA (2 ops) stays in flight across the barrier
         vm_wait<2>(e, p);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const f32x4 *rd = ldsb + slot_rd * FWD_BCHUNK + roff;
-        const int a2 = aoff(ca);
+        const f32x4 *rd = ldsb + ((c8 + 1) & (FWD_NBUF - 1)) * FWD_BCHUNK + roff;
+        const int a2 = (c8 + 2 >= last) ? a_last : 8 * (c8 + 2);  // A slice of step c8+2 (clamped)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q < 4) {
@@ -208,16 +214,13 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
                 asm_load16(e, erow + a2);
                 if (!USE_HID) asm_load16(p, prow + a2);
                 __builtin_amdgcn_sched_barrier(0);
-                dma(cdma, slot_wr);
+                dma(wnext, (c8 + 3) & (FWD_NBUF - 1));  // step c8+3's B
+                if (c8 + 4 < HK) wnext += wstride_b;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) a_cur[s] = a_nxt[s];
-        ca = nextc(ca);
-        cdma = nextc(cdma);
-        slot_rd = (slot_rd + 1) & (FWD_NBUF - 1);
-        slot_wr = (slot_wr + 1) & (FWD_NBUF - 1);
     }
     // drain the DMA that ran ahead past the last step before the ring is reused / the
     // workgroup exits, and make sure every wave is done reading
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         (float(*)[FWD_ROWS])(smem + FWD_NBUF * FWD_BCHUNK * 16 + 16 * FWD_THREADS * 8);
     float(*s_s)[FWD_ROWS] = s_m + 2;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: M0 of the DMAs, no per-use readfirstlane
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
     const int b = blockIdx.y;
@@ -297,7 +301,6 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     const long wstride = (long)NG * 256;  // float4 per 8-wide k chunk
     const int npass = (NG + 3) / 4;
 
-    const int rot = (int)(((unsigned)blockIdx.x * 5u + (unsigned)blockIdx.y * 11u) % (unsigned)HK);
 
     for (int pass = 0; pass < npass; ++pass) {
         const int ng0 = pass * 4 + wn * 2;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
         const int gvalid = min(4, NG - pass * 4);
         STAMP(1 + 2 * (pass & 1));
-        fwd_mainloop<USE_HID>(erow, prow, wpass, gvalid, HK, wstride, H, half, rot, wave, lane, wn,
+        fwd_mainloop<USE_HID>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
                                 s_b, acc);
         STAMP(2 + 2 * (pass & 1));
 
