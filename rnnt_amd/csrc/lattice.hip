@@ -104,21 +104,37 @@ __device__ __forceinline__ void lattice_sweep(
     double *out = out_s + base;
     const bool col_ok = (u <= Ub);
 
-    // fetch the lp pair step k consumes (k counts steps: diagonal d = k for alpha,
-    // d = nd-1-k for beta); zero when the cell or its neighbour is outside the lattice.
+    // The step is a chain of dependent instructions on one wave per SIMD, so its length is what
+    // a diagonal costs: no divergent branches (selects only), unconditional clamped loads, and
+    // the lattice boundary handled by the data — cells outside the lattice hold -inf in the LDS
+    // line, so "no such neighbour" needs no test.
+    // lp pair step k consumes (k counts steps: diagonal d = k for alpha, d = nd-1-k for beta);
+    // 0 when the cell or the transition does not exist (the arrays are only written for lattice
+    // cells: whatever else they hold must not reach the arithmetic).
     auto fetch = [&](int k, float &lb, float &le) {
-        lb = 0.f; le = 0.f;
-        if (k >= nd) return;
-        const int d = DIR == 0 ? k : nd - 1 - k;
+        const int kk = k < nd ? k : nd - 1;
+        const int d = DIR == 0 ? kk : nd - 1 - kk;
         const int t = d - u;
-        if (!(col_ok && t >= 0 && t < Tb)) return;
+        const bool cell = (k < nd) && col_ok && t >= 0 && t < Tb;
+        const int uc = u < U1 ? u : U1 - 1;  // the block is padded to whole waves: stay inside the row
         if (DIR == 0) {
-            if (t > 0) lb = lpb[(long)(d - 1) * U1 + u];
-            if (u > 0) le = lpe[(long)(d - 1) * U1 + u - 1];
+            const int dr = d > 0 ? d - 1 : 0;
+            const float vb = lpb[(long)dr * U1 + uc];
+            const float ve = lpe[(long)dr * U1 + (uc > 0 ? uc - 1 : 0)];
+            lb = (cell && t > 0) ? vb : 0.f;
+            le = (cell && u > 0) ? ve : 0.f;
         } else {
-            lb = lpb[(long)d * U1 + u];
-            if (u < Ub) le = lpe[(long)d * U1 + u];
+            const float vb = lpb[(long)d * U1 + uc];
+            const float ve = lpe[(long)d * U1 + uc];
+            lb = cell ? vb : 0.f;
+            le = (cell && u < Ub) ? ve : 0.f;
         }
+    };
+    // -inf-safe log(exp(a) + exp(e)): the correction term is evaluated in fp32 (it is < ln 2)
+    auto lae = [&](double a, double e) {
+        const double m = fmax(a, e);
+        const float dl = (m == NINF) ? 0.f : (float)(fmin(a, e) - m);
+        return m + (double)__logf(1.0f + __expf(dl));
     };
     auto step = [&](int k, float lb, float le) {
         const double *prev = buf[(k & 1) ^ 1];
@@ -126,34 +142,21 @@ __device__ __forceinline__ void lattice_sweep(
         const int d = DIR == 0 ? k : nd - 1 - k;
         const int t = d - u;
         const bool valid = (k < nd) && col_ok && t >= 0 && t < Tb;
-        double val = NINF;
-        if (DIR == 0) {
-            const double up = prev[u + 1];  // alpha[t-1,u]
-            const double left = prev[u];    // alpha[t,u-1]
-            if (valid) {
-                if (d == 0) val = 0.0;
-                else {
-                    const double a = (t > 0) ? up + (double)lb : NINF;
-                    const double e = (u > 0) ? left + (double)le : NINF;
-                    val = logaddexp_mixed(a, e);
-                }
-            }
-        } else {
-            const double down = prev[u + 1];   // beta[t+1,u]
-            const double right = prev[u + 2];  // beta[t,u+1]
-            if (valid) {
-                if (t == Tb - 1 && u == Ub) val = (double)lb;
-                else {
-                    const double a = (t < Tb - 1) ? down + (double)lb : NINF;
-                    const double e = (u < Ub) ? right + (double)le : NINF;
-                    val = logaddexp_mixed(a, e);
-                }
-            }
-        }
+        // alpha: prev[u+1] = alpha[t-1,u], prev[u] = alpha[t,u-1]
+        // beta:  prev[u+1] = beta[t+1,u],  prev[u+2] = beta[t,u+1]
+        const double a = prev[u + 1] + (double)lb;
+        const double e = prev[DIR == 0 ? u : u + 2] + (double)le;
+        double val = lae(a, e);
+        // the first cell of each sweep has no predecessor: alpha[0,0] = 0, beta[Tb-1,Ub] = lp_blank
+        if (k == 0) val = DIR == 0 ? 0.0 : (double)lb;  // k is uniform; only one thread is valid
+        val = valid ? val : NINF;
         cur[u + 1] = val;
         if (k < nd && u < U1) out[(long)d * U1 + u] = val;
         if (DIR == 1 && k == nd - 1 && u == 0) costs[b] = (float)(-val);
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() would also wait for vmcnt(0), i.e. for this step's
+        // store and for the lp prefetch of four steps ahead
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
 
     float lb0, le0, lb1, le1, lb2, le2, lb3, le3;
