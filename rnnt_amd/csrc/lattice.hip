@@ -134,7 +134,9 @@ __device__ __forceinline__ void lattice_sweep(
     auto lae = [&](double a, double e) {
         const double m = fmax(a, e);
         const float dl = (m == NINF) ? 0.f : (float)(fmin(a, e) - m);
-        return m + (double)__logf(1.0f + __expf(dl));
+        // hardware exp2/log2 directly: the argument of the log is in (1, 2], no range fix-ups
+        // (logf/__logf expand to ~15 instructions of them) in this serial chain
+        return m + (double)(__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(dl * RNNT_LOG2E)) * 0.6931471805599453f);
     };
     auto step = [&](int k, float lb, float le) {
         const double *prev = buf[(k & 1) ^ 1];
