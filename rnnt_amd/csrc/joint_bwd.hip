@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void k_make_hidden(const float *__restrict__ e
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[q] + p[q]);
     }
-    *(f32x4 *)(hid + c * H + h) = o;
+    __builtin_nontemporal_store(o, (f32x4 *)(hid + c * H + h));  // 13 GB streamed once: keep it out of the caches
 }
 
 __global__ __launch_bounds__(256) void k_make_g(float *__restrict__ logits,
