@@ -40,6 +40,40 @@ __device__ __forceinline__ float half_sum(float v)
     return v;
 }
 
+// The same reductions on the DPP crossbar (VALU rate, no LDS round trip: __shfl_xor lowers to
+// ds_bpermute_b32): quad_perm xor 1, xor 2, row_ror 4, 8 give every lane its 16-lane row's
+// result; row_bcast15 into rows 1 and 3 completes the 32-lane half in lanes 16-31 / 48-63;
+// half_bcast() hands that to every lane of the half.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float half_bcast(float v, int half)
+{
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return half ? hi : lo;
+}
+__device__ __forceinline__ float half_max_dpp(float v, int half)
+{
+    v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x124, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x128, 0xf>(v, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xa>(RNNT_NEG_INF, v));
+    return half_bcast(v, half);
+}
+__device__ __forceinline__ float half_sum_dpp(float v, int half)  // valid in lanes 16-31 / 48-63
+{
+    v += dpp_mov<0xB1, 0xf>(v, v);
+    v += dpp_mov<0x4E, 0xf>(v, v);
+    v += dpp_mov<0x124, 0xf>(v, v);
+    v += dpp_mov<0x128, 0xf>(v, v);
+    v += dpp_mov<0x142, 0xa>(0.f, v);
+    return v;
+}
+
 // Packed per-cell gradient coefficients written by k_coef, read by the backward GEMMs:
 //   G[v] = exp2(logit[v]*log2e + c1) - (v==blank)*sb - (v==y)*se
 struct __attribute__((aligned(16))) CellCoef {

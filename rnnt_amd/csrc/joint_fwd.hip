@@ -380,19 +380,18 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
             const float2 ms = s_run2[r][tid];
             m_run[r] = ms.x; s_run[r] = ms.y;
         }
+        // row max over the 32 lanes, per-lane sums rescaled to it, row sum — on the DPP crossbar
+        // (the butterfly of (max, sum) pairs through ds_bpermute was ~1100 instructions here)
 #pragma unroll
-        for (int k = 16; k >= 1; k >>= 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float mo = __shfl_xor(m_run[r], k, 64), so = __shfl_xor(s_run[r], k, 64);
-                const float mn = fmaxf(m_run[r], mo);
-                const float e1 = (m_run[r] == RNNT_NEG_INF) ? 0.f : __expf(m_run[r] - mn);
-                const float e2 = (mo == RNNT_NEG_INF) ? 0.f : __expf(mo - mn);
-                s_run[r] = s_run[r] * e1 + so * e2;
-                m_run[r] = mn;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float M = half_max_dpp(m_run[r], half);
+            // exp2(-inf - M) = 0 for lanes (and rows) that saw nothing; a row that is -inf
+            // everywhere keeps M = -inf and a zero sum
+            const float sc = (m_run[r] == RNNT_NEG_INF) ? 0.f : __builtin_amdgcn_exp2f((m_run[r] - M) * RNNT_LOG2E);
+            s_run[r] = half_sum_dpp(s_run[r] * sc, half);
+            m_run[r] = M;
         }
-        if (i == 0) {
+        if (i == 31) {  // lanes 31 / 63 hold the sums of their half
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rowl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
