@@ -353,13 +353,12 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
                     ml = fmaxf(ml, fmaxf(fmaxf(acc[4][r], acc[5][r]), fmaxf(acc[6][r], acc[7][r])));
                 const float2 ms = s_run2[r][tid];
                 const float mn = fmaxf(ms.x, ml);
-                float sl = __expf(acc[0][r] - mn) + __expf(acc[1][r] - mn) +
-                           __expf(acc[2][r] - mn) + __expf(acc[3][r] - mn);
-                if (cok[1])
-                    sl += __expf(acc[4][r] - mn) + __expf(acc[5][r] - mn) +
-                          __expf(acc[6][r] - mn) + __expf(acc[7][r] - mn);
-                // exp(-inf - finite) = 0 on the first pass
-                s_run2[r][tid] = make_float2(mn, ms.y * __expf(ms.x - mn) + sl);
+                const float nm2 = -mn * RNNT_LOG2E;  // exp(x - mn) = exp2(fma(x, log2e, nm2)): 2 instructions
+                auto ex = [&](float x) { return __builtin_amdgcn_exp2f(fmaf(x, RNNT_LOG2E, nm2)); };
+                float sl = (ex(acc[0][r]) + ex(acc[1][r])) + (ex(acc[2][r]) + ex(acc[3][r]));
+                if (cok[1]) sl += (ex(acc[4][r]) + ex(acc[5][r])) + (ex(acc[6][r]) + ex(acc[7][r]));
+                // exp2(-inf * log2e + finite) = 0 on the first pass
+                s_run2[r][tid] = make_float2(mn, ms.y * ex(ms.x) + sl);
             }
         }
     }
