@@ -498,43 +498,69 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.hidden + cell0 * H), 0, (int)(span_rows * H * 4), 0x00020000);
+    const unsigned hvoff[2] = {colok[0] ? (unsigned)(((4 * half) * H + colg[0]) * 4) : 0xfffffff0u,
+                               colok[1] ? (unsigned)(((4 * half) * H + colg[1]) * 4) : 0xfffffff0u};
+    // Four batches (one t-row of the wave each) of 16 hidden loads, two batches in flight: each
+    // batch otherwise waits out a full memory round trip (4 x ~6 000 cycles per tile, stamps).
+    auto hload = [&](int k, f32x4 (&hb)[16]) {  // k = mt*2 + rh
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int r7 = 0; r7 < 8; ++r7) {
+            // hidden row of (t, u = u0 + 8(r7>>2) + 4half + (r7&3)) through the tile buffer:
+            // scalar row offset + per-lane (half, column) offset, no predicate — rows outside
+            // the lattice have G = 0, hence an exactly zero accumulator, whatever (finite, or
+            // out of range -> 0) hidden value they meet
+            const unsigned soff = (unsigned)(((wm * 4 + k) * U1 + 8 * (r7 >> 2) + (r7 & 3)) * H) * 4u;
 #pragma unroll
-        for (int rh = 0; rh < 2; ++rh) {
-            const int t = t0 + wm * 4 + mt * 2 + rh;
-            const bool tok = t < Tb;
-            float esum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 2; ++g)
+                hb[r7 * 2 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hvoff[g], soff, 0));
+        }
+    };
+    auto hcomp = [&](int k, const f32x4 (&hb)[16]) {
+        const int mt = k >> 1, rh = k & 1;
+        const int t = t0 + wm * 4 + k;
+        const bool tok = t < Tb;
+        float esum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r7 = 0; r7 < 8; ++r7) {
-                const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
-                const bool rok = tok && u < U1;
-                const float *hrow = a.hidden + (((long)b * T + (rok ? t : 0)) * U1 + (rok ? u : 0)) * H;
+        for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const bool ok = rok && colok[g];
-                    f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) h4 = *(const f32x4 *)(hrow + colg[g]);
+            for (int g = 0; g < 2; ++g) {
+                const f32x4 h4 = hb[r7 * 2 + g];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float d =
-                            ok ? acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
-                        esum[g * 4 + q] += d;
-                        psum[r7][g * 4 + q] += d;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const float d = acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - h4[q] * h4[q]);
+                    esum[g * 4 + q] += d;
+                    psum[r7][g * 4 + q] += d;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
-            if (half == 0 && tok) {
+        for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
+        if (half == 0 && tok) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (colok[g]) {
-                        f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
-                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
-                    }
-            }
+            for (int g = 0; g < 2; ++g)
+                if (colok[g]) {
+                    f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
+                    *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
+                }
         }
+    };
+    {
+        f32x4 hA[16], hB[16];
+        hload(0, hA);
+        hload(1, hB);
+        __builtin_amdgcn_sched_barrier(0);
+        hcomp(0, hA);
+        __builtin_amdgcn_sched_barrier(0);
+        hload(2, hA);
+        __builtin_amdgcn_sched_barrier(0);
+        hcomp(1, hB);
+        __builtin_amdgcn_sched_barrier(0);
+        hload(3, hB);
+        __builtin_amdgcn_sched_barrier(0);
+        hcomp(2, hA);
+        hcomp(3, hB);
+    }
     if (wm == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
