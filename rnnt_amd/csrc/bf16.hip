@@ -504,6 +504,30 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     if (a.flags & 8192) return;
     float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+    // All 32 hidden fragments of the epilogue requested up front through a raw buffer over the
+    // tile's rows (scalar row offset + per-lane offset, no predicates: one memory round trip
+    // instead of four; rows outside the lattice have G = 0 and therefore an exactly zero
+    // accumulator, whatever finite — or, out of range, zero — hidden value they meet).
+    u32x2 hq[2][2][8];
+    {
+        const long cell0 = ((long)b * T + t0) * U1 + u0;
+        const long rows_left = a.rows_alloc - cell0;
+        const long span = (long)(BG_BT - 1) * U1 + BG_BU < rows_left ? (long)(BG_BT - 1) * U1 + BG_BU : rows_left;
+        const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.hidden + cell0 * H), 0, (int)(span * H * 2), 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int col0 = 256 * wn + 128 * g + 4 * j;
+            const unsigned voff = col0 < H ? (unsigned)(((4 * half) * H + col0) * 2) : 0xfffffff0u;
+#pragma unroll
+            for (int tl_ = 0; tl_ < 2; ++tl_)
+#pragma unroll
+                for (int r7 = 0; r7 < 8; ++r7) {
+                    const unsigned soff = (unsigned)(((2 * wm + tl_) * U1 + (r7 & 3) + 8 * (r7 >> 2)) * H) * 2u;
+                    hq[g][tl_][r7] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, voff, soff, 0));
+                }
+        }
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int col0 = 256 * wn + 128 * g + 4 * j;
@@ -520,15 +544,12 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
             float esum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r7 = 0; r7 < 8; ++r7) {
-                const int u = u0 + (r7 & 3) + 8 * (r7 >> 2) + 4 * half;
-                const bool ok = tok && u < U1 && colok;
-                u32x2 h2 = {0u, 0u};
-                if (ok) h2 = *(const u32x2 *)(a.hidden + (((long)b * T + t) * U1 + u) * H + col0);
+                const u32x2 h2 = hq[g][tl_][r7];
                 const float hv[4] = {bf16_lo(h2[0]), bf16_hi(h2[0]), bf16_lo(h2[1]), bf16_hi(h2[1])};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float av = acc[4 * g + q][tl_ * 8 + r7];
-                    const float d = ok ? av * (1.f - hv[q] * hv[q]) : 0.f;
+                    const float d = av * (1.f - hv[q] * hv[q]);
                     esum[q] += d;
                     psum[r7][q] += d;
                 }
