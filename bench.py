@@ -52,7 +52,7 @@ def synth(B, T, U, H, V, seed, device):
     return [x.to(device) for x in (enc, pred, W, bias, targets, ll, tl)]
 
 
-def cpu_baseline(T, U, H, V, budget_s=20.0):
+def cpu_baseline(T, U, H, V, budget_s=40.0):
     """CPU port of the same path on this box's host cores: the reference's own torch-CPU op
     sequence for the joint (oracle/torch_check.joint_torch == rnnt/joint.py:32-39) with torch
     autograd, and the C restatement of the loss (oracle/rnnt_oracle.c, fp32, OpenMP over
@@ -76,7 +76,8 @@ def cpu_baseline(T, U, H, V, budget_s=20.0):
     one(1, max(8, T // 50))  # warm-up (thread pools, allocator)
     t_probe = one(1, max(8, T // 10))
     est_full = t_probe * 10.0  # one utterance at full T
-    B = int(max(1, min(8, budget_s // max(est_full, 1e-3))))  # ~10-30 s of CPU work
+    # ~10-30 s of CPU work: the probe over-estimates (thread pools warm up), so aim at the top
+    B = int(max(1, min(8, round(budget_s / max(est_full, 1e-3)))))
     dt = one(B, T)
     return {"value": B * T * U / dt, "unit": "cells/s", "cores": threads, "kind": "port",
             "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, 1 run of joint(torch CPU)+loss(C oracle) "
