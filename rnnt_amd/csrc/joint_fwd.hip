@@ -152,16 +152,16 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
     // beyond the last valid one of a partial pass re-read group 0 (their tiles are discarded)
     const int dgrp = wave >> 1;
     const unsigned dlane = (unsigned)(((dgrp < gvalid ? wave * 128 : (wave & 1) * 128) + lane) * 16);  // bytes
-    // LDS-DMA as buffer loads: descriptor + scalar chunk offset + constant per-lane offset, so a
-    // chunk's two pieces need one M0 and no vector address arithmetic (the second piece is the
-    // first at instruction offset 1024, which moves the global AND the LDS address)
+    // LDS-DMA: the chunk's two 1 KiB pieces share one address and one M0 — the second is the
+    // first at instruction offset 1024, which moves the global AND the LDS address.  (As MUBUF
+    // `buffer_load ... lds` with a scalar chunk offset the address arithmetic disappears too, but
+    // hipcc then guards every following ds_read with an s_waitcnt lgkmcnt.)
     const unsigned wstride_b = (unsigned)(wstride * 16);
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)wpass, 0, (int)((unsigned)HK * wstride_b), 0x00020000);
+    const char *wlane = (const char *)wpass + dlane;  // per-lane source of chunk 0
     auto dma = [&](unsigned chunk_off, int slot) {  // chunk_off: uniform byte offset of the chunk
         f32x4 *dst = ldsb + slot * FWD_BCHUNK + wave * 128;  // wave-uniform (goes to M0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_ptr)dst, 16, dlane, chunk_off, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_ptr)dst, 16, dlane, chunk_off, 1024, 0);
+        __builtin_amdgcn_global_load_lds((const void *)(wlane + chunk_off), (lds_void_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void *)(wlane + chunk_off), (lds_void_ptr)dst, 16, 1024, 0);
     };
     const int roff = wn * 512 + lane;  // this wave's first fragment inside a staged chunk
     unsigned wnext = 0;  // byte offset of the chunk the next DMA fetches
