@@ -51,7 +51,8 @@ extern "C" {
 /* Library version (RNNT_ENGINE_VERSION it was built with). */
 int rnnt_engine_version(void);
 
-/* Tuning/experiment switches (bit 0: non-temporal logits stores). Returns the old value. */
+/* Experiment switches read by the ablation code of diagnostic builds (-DRNNT_ABLATE; the shipped
+ * kernels ignore them), and bit 5 (32): force the separate k_make_g pass.  Returns the old value. */
 int rnnt_engine_set_flags(int flags);
 
 /* Device buffer for diagnostic in-kernel time stamps; only read by builds made with

@@ -241,16 +241,16 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         for (int q = 0; q < 4; ++q) {
             // stage chunk cc+q+1 into the other slot, fetch chunk cc+q+3
             const long nxt = cc + q + 3 < NC ? cc + q + 3 : NC - 1;
-            if (q & 1) { bx.store(s_b[0], wave, lane); bx.load(wp, nxt, wave, lane, !(a.flags & 2048)); }
-            else       { by.store(s_b[1], wave, lane); by.load(wp, nxt, wave, lane, !(a.flags & 2048)); }
+            if (q & 1) { bx.store(s_b[0], wave, lane); bx.load(wp, nxt, wave, lane, !RNNT_XP(a.flags, 2048)); }
+            else       { by.store(s_b[1], wave, lane); by.load(wp, nxt, wave, lane, !RNNT_XP(a.flags, 2048)); }
             // A fragments of chunk cc+q+3 (same rows, k wraps into the next pass)
-            if (!(a.flags & 4096)) {
+            if (!RNNT_XP(a.flags, 4096)) {
                 int c3 = c + q + 3; if (c3 >= KC) c3 -= KC;
                 ar[(q + 3) & 3][0] = ap[4 * c3];
                 ar[(q + 3) & 3][1] = ap[4 * c3 + 1];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!(a.flags & 1024)) mma_chunk<NT, 5>(acc, ar[q][0], ar[q][1], s_b[q & 1], lane);
+            if (!RNNT_XP(a.flags, 1024)) mma_chunk<NT, 5>(acc, ar[q][0], ar[q][1], s_b[q & 1], lane);
             if (q == 3 && c + 4 == KC) {  // pass complete (KC % 4 == 0): bias, store, softmax statistics
                 const bool g1 = 256 * pass + 128 < V;  // V % 128 == 0: a 128-column group is all in or out
                 const int col0 = 256 * pass + 4 * j;
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
                     const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const f32x4 o0 = {acc[0][r] + b0[0], acc[1][r] + b0[1], acc[2][r] + b0[2], acc[3][r] + b0[3]};
                     f32x4 o1 = {acc[4][r] + b1[0], acc[5][r] + b1[1], acc[6][r] + b1[2], acc[7][r] + b1[3]};
-                    if (!(a.flags & 256)) {
-                        if (!(a.flags & 1)) {  // streaming stores: the logits are not re-read by this kernel's CUs
+                    if (!RNNT_XP(a.flags, 256)) {
+                        if (!RNNT_XP(a.flags, 1)) {  // streaming stores: the logits are not re-read by this kernel's CUs
                                               // and should not evict the A rows the next pass re-reads from L2
                             __builtin_nontemporal_store(o0, (f32x4 *)(a.logits + orow * V + col0));
                             if (g1) __builtin_nontemporal_store(o1, (f32x4 *)(a.logits + orow * V + col0 + 128));
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
                         }
                     }
                     if (!g1) o1 = o0;  // duplicates only feed the max; their exp terms are dropped below
-                    if (a.flags & 512) continue;
+                    if (RNNT_XP(a.flags, 512)) continue;
                     // running (max, sum exp) of this lane's columns of row-slot r
                     const float lmax = fmaxf(fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3])),
                                              fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
         }
         const u32x4 o = {pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3]), pack_bf16(g[4], g[5]), pack_bf16(g[6], g[7])};
         s_g[slot * 512 + gdst] = o;
-        if (pexists && c < VC && !(a.flags & 256)) grow[4 * c] = o;
+        if (pexists && c < VC && !RNNT_XP(a.flags, 256)) grow[4 * c] = o;
     };
     auto wload = [&](u32x4 (&w)[4], int c) {
         const u32x4 *p = wp + (long)(c < VC ? c : VC - 1) * 2048;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
 
     // ---- epilogue.  Accumulator register r of tile 4g+q (g = 0,1): row (r&3) + 8(r>>2) + 4*half
     // of M-tile wm = (t-row 2wm + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 256wn + 128g + 4j + q.
-    if (a.flags & 8192) return;
+    if (RNNT_XP(a.flags, 8192)) return;
     float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
     // All 32 hidden fragments of the epilogue requested up front through a raw buffer over the
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         };
         struct Frags { u32x2 al[4], ah[4], bl[4], bh[4]; };
         auto reads = [&](Frags &f, int slot, int ks) {  // 16 transposed reads, NOT waited for
-            if (a.flags & 4096) return;  // experiment switch
+            if (RNNT_XP(a.flags, 4096)) return;  // experiment switch
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int a0 = a_tile + slot * 32768 + 4096 * ks, b0 = b_tile + slot * 32768 + 4096 * ks;
@@ -730,14 +730,14 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             }
 #pragma unroll
             for (int qm = 0; qm < 4; ++qm) {
-                if (!(a.flags & 1024)) {
+                if (!RNNT_XP(a.flags, 1024)) {
 #pragma unroll
                     for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = mfma_bf16(fa[qm], fb[qn], acc[qm][qn]);
                 }
-                if (!(a.flags & 8192)) dma_piece(dst, dslot, piece0 + qm);
+                if (!RNNT_XP(a.flags, 8192)) dma_piece(dst, dslot, piece0 + qm);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (do_b && !(a.flags & 2048)) {
+            if (do_b && !RNNT_XP(a.flags, 2048)) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll

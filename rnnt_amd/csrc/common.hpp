@@ -7,6 +7,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define RNNT_NEG_INF (-__builtin_inff())
+// Ablation switches (rnnt_engine_set_flags) exist only in diagnostic builds
+// (make EXTRA=-DRNNT_ABLATE, used by tools/exp_*.py); the shipped kernels carry none.
+#ifdef RNNT_ABLATE
+#define RNNT_XP(flags, bit) ((flags) & (bit))
+#else
+#define RNNT_XP(flags, bit) (0)
+#endif
 #define RNNT_LOG2E 1.4426950408889634f
 
 // Skewed ("anti-diagonal major") lattice layout used by every per-cell work array the

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
                                                                           0, 0, 0);
                 }
         };
-        const bool xp_noepi = (a.flags & 4) != 0;  // experiment switch
+        const bool xp_noepi = RNNT_XP(a.flags, 4) != 0;  // experiment switch
         PwChunk r0, r1;
         load(r0, 0);
         load(r1, 1);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     GSTAMP(2);
 
     // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
-    if (a.flags & 8192) return;  // experiment switch
+    if (RNNT_XP(a.flags, 8192)) return;  // experiment switch
     float psum[8][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
                 if (rv && cok[g]) {
                     f32x4 o = {acc[g * 4 + 0][r], acc[g * 4 + 1][r], acc[g * 4 + 2][r],
                                acc[g * 4 + 3][r]};
-                    if (a.flags & 1)
+                    if (RNNT_XP(a.flags, 1))
                         __builtin_nontemporal_store(o, (f32x4 *)(lrow + col0[g]));
                     else
                         *(f32x4 *)(lrow + col0[g]) = o;

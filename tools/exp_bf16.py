@@ -1,4 +1,4 @@
-"""Experiment: bf16 stage times with parts switched off (rnnt_engine_set_flags bits 256 no stores,
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: bf16 stage times with parts switched off (rnnt_engine_set_flags bits 256 no stores,
 512 no statistics, 1024 no MFMA, 8192 no dHidden epilogue)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Experiment: bf16 dHidden stage with G stores / epilogue switched off."""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: bf16 dHidden stage with G stores / epilogue switched off."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

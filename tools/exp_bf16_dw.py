@@ -1,4 +1,4 @@
-"""Experiment: bf16 dW stage with / without MFMA (valid G in the workspace)."""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: bf16 dW stage with / without MFMA (valid G in the workspace)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

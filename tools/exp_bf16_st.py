@@ -1,4 +1,4 @@
-"""Experiment: do the G / logits stores cost time by themselves or through the in-order vmcnt?"""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: do the G / logits stores cost time by themselves or through the in-order vmcnt?"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

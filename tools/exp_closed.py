@@ -1,4 +1,4 @@
-"""Diagnostic: closed-form cost check at cfg2 size, several runs, report every mismatch."""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Diagnostic: closed-form cost check at cfg2 size, several runs, report every mismatch."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

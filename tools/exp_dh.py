@@ -1,4 +1,4 @@
-"""Experiment: dHidden stage time with loads / epilogue switched off (rnnt_engine_set_flags)."""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: dHidden stage time with loads / epilogue switched off (rnnt_engine_set_flags)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

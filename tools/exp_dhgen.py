@@ -1,4 +1,4 @@
-"""Experiment: fp32 k_dhidden_gen stage with G stores / logits loads / epilogue switched off."""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: fp32 k_dhidden_gen stage with G stores / logits loads / epilogue switched off."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

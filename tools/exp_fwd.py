@@ -1,4 +1,4 @@
-"""Experiment: time the plain joint forward (no softmax epilogue) vs fused stage 0 at cfg2."""
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Experiment: time the plain joint forward (no softmax epilogue) vs fused stage 0 at cfg2."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

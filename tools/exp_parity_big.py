@@ -1,4 +1,4 @@
-"""Diagnostic: loss of the fused and the unfused GPU paths vs the fp64 oracle at a mid size
+"""[needs a diagnostic build: make -C rnnt_amd/csrc clean && make -C rnnt_amd/csrc EXTRA=-DRNNT_ABLATE] Diagnostic: loss of the fused and the unfused GPU paths vs the fp64 oracle at a mid size
 (long lattice, full H and V), loss only (oracle forward is OpenMP-parallel)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
