@@ -785,34 +785,46 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
         const float *gp = a.logits + (k_lo * DW_KC + half) * (long)V + (vok ? vbase : V - 4);
         const float *hp = a.hidden + (k_lo * DW_KC + half) * (long)H + (hok ? hbase : H - 4);
         const long gstep = 2L * V, hstep = 2L * H;
-        // Register ring of DW_RING k-steps: copy the slot out, refill it, then issue the MFMAs.
-        // Measured alternatives: refilling a slot right behind its own MFMAs (the load blocks
-        // until the in-flight MFMAs stop reading it: 50.7 ms), delayed in-place refill (hipcc
-        // still rotates registers and drains with vmcnt(0): 50.7 ms), inline-asm loads (hipcc
-        // copies the pending destinations) — this form: 47.4 ms.
+        // Register ring of DW_RING k-steps.  The MFMAs read their ring slot directly; the slot
+        // is refilled one k-step LATER, from inside the next k-step's MFMA stream (its own MFMAs
+        // have all issued by then, so the load does not wait on them), and the bias-gradient
+        // adds ride between MFMAs too: nothing stands in front of a k-step's 16 MFMAs.
+        // (Earlier forms: copy the slot out + refill in front of the MFMAs 47.4 ms; refill right
+        // behind its own MFMAs 50.7 ms; inline-asm loads: hipcc copies pending destinations.)
         f32x4 ra[DW_RING], rb[DW_RING];
 #pragma unroll
         for (int s_ = 0; s_ < DW_RING; ++s_) {
             ra[s_] = *(const f32x4 *)(gp + s_ * gstep);
             rb[s_] = *(const f32x4 *)(hp + s_ * hstep);
         }
-        gp += DW_RING * gstep;
+        gp += DW_RING * gstep;  // -> k-step DW_RING
         hp += DW_RING * hstep;
         for (long st = 0; st < nstep; st += DW_RING) {
 #pragma unroll
             for (int s_ = 0; s_ < DW_RING; ++s_) {
-                const f32x4 a4 = ra[s_], b4 = rb[s_];
-                ra[s_] = *(const f32x4 *)(gp + s_ * gstep);  // k-step st + s_ + DW_RING
-                rb[s_] = *(const f32x4 *)(hp + s_ * hstep);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int qm = 0; qm < 4; ++qm) {
-                    dbacc[qm] += a4[qm];
+                auto row = [&](int qm) {
 #pragma unroll
                     for (int qn = 0; qn < 4; ++qn)
-                        acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qm], b4[qn],
-                                                                           acc[qm][qn], 0, 0, 0);
+                        acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s_][qm], rb[s_][qn], acc[qm][qn], 0, 0, 0);
+                };
+                row(0);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // refill the previous slot with k-step st + s_ - 1 + DW_RING (at the very first
+                    // step that re-reads k-step DW_RING-1 into the slot that already holds it)
+                    const int ps = (s_ + DW_RING - 1) % DW_RING;
+                    ra[ps] = *(const f32x4 *)(gp + (s_ - 1) * gstep);
+                    rb[ps] = *(const f32x4 *)(hp + (s_ - 1) * hstep);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                row(1);
+                dbacc[0] += ra[s_][0];
+                dbacc[1] += ra[s_][1];
+                __builtin_amdgcn_sched_barrier(0);
+                row(2);
+                dbacc[2] += ra[s_][2];
+                dbacc[3] += ra[s_][3];
+                __builtin_amdgcn_sched_barrier(0);
+                row(3);
                 __builtin_amdgcn_sched_barrier(0);
             }
             gp += DW_RING * gstep;
