@@ -133,7 +133,8 @@ __device__ __forceinline__ void vm_wait(f32x4 &e, f32x4 &p)
 // no difference and was dropped with its wrap-around arithmetic.)  W is zero-padded in wpack,
 // tanh of any finite input is finite, and address clamps keep every load in bounds, so no load
 // in the loop is conditional.
-template <bool USE_HID>  // true: erow points at the precomputed hidden row (no tanh, no pred)
+template <bool USE_HID, bool PAIRS>  // USE_HID: erow points at the precomputed hidden row (no tanh, no pred)
+                                     // PAIRS (with USE_HID, even chunk count): two-set form below
 __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *prow,
                                              const f32x4 *wpass, int gvalid, int HK,
                                              long wstride, int H, int half, int wave,
@@ -167,6 +168,60 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
     unsigned wnext = 0;  // byte offset of the chunk the next DMA fetches
 
     f32x4 w[8];
+    if constexpr (USE_HID && PAIRS) {
+        // Hot path (A = precomputed hidden rows): the MFMAs read the loaded registers themselves.
+        // Two register sets alternate by chunk parity: chunk c8 multiplies set c8&1 and, when its
+        // last MFMA has issued, re-requests that set for chunk c8+2 — a whole chunk of slack, no
+        // conversion, no copies (8 v_mov per chunk in the generic form below).
+        f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = {0.f, 0.f, 0.f, 0.f};
+        auto aoff = [&](int c) { return c >= last ? a_last : 8 * c; };
+        dma(wnext, 0);
+        if (HK > 1) wnext += wstride_b;
+        dma(wnext, 1);
+        if (HK > 2) wnext += wstride_b;
+        asm_load16(ea, erow + aoff(0));
+        vm_wait<0>(ea, eb);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = ldsb[roff + q * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        dma(wnext, 2);
+        if (HK > 3) wnext += wstride_b;
+        asm_load16(eb, erow + aoff(1));
+        __builtin_amdgcn_sched_barrier(0);
+        // per chunk this wave issues: 2 DMA pieces (at q == 3), then 1 A load (after the last
+        // MFMA).  At the top of chunk c8 the 3 ops of chunk c8-1 may stay in flight; everything
+        // older — this chunk's A (requested at the end of c8-2) and the B of chunk c8+1 — is in.
+        auto chunk = [&](int c8, f32x4 &eu) {
+            vm_wait<3>(ea, eb);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 *rd = ldsb + ((c8 + 1) & (FWD_NBUF - 1)) * FWD_BCHUNK + roff;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(eu[s], w[q][s], acc[q], 0, 0, 0);
+                w[q] = rd[q * 64];
+                if (q == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma(wnext, (c8 + 3) & (FWD_NBUF - 1));  // step c8+3's B
+                    if (c8 + 4 < HK) wnext += wstride_b;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm_load16(eu, erow + aoff(c8 + 2));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int c8 = 0; c8 < HK; c8 += 2) {
+            chunk(c8, ea);
+            chunk(c8 + 1, eb);
+        }
+        vm_wait<0>(ea, eb);
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
     float a_cur[4], a_nxt[4];
     dma(wnext, 0);
     if (HK > 1) wnext += wstride_b;
@@ -247,7 +302,7 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
 #define STAMP(slot)
 #endif
 
-template <bool WITH_LOSS, bool USE_HID>
+template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false>
 __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
 {
     // ALL LDS in one array (hipcc otherwise guards every ds_read with vmcnt(0) while an LDS-DMA
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
         const int gvalid = min(4, NG - pass * 4);
         STAMP(1 + 2 * (pass & 1));
-        fwd_mainloop<USE_HID>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
+        fwd_mainloop<USE_HID, PAIRS>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
                                 s_b, acc);
         STAMP(2 + 2 * (pass & 1));
 
@@ -432,7 +487,10 @@ void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
     const int tiles = (int)(((long)a.T * a.U1 + FWD_ROWS - 1) / FWD_ROWS);
     dim3 grid(tiles, a.B), block(FWD_THREADS);
     if (a.denom_s && a.hidden)
-        hipLaunchKernelGGL((k_joint_fwd<true, true>), grid, block, 0, st, a);
+        if (((a.H + 7) / 8) % 2 == 0)  // even number of 8-wide chunks: the two-register-set main loop
+            hipLaunchKernelGGL((k_joint_fwd<true, true, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_joint_fwd<true, true>), grid, block, 0, st, a);
     else if (a.denom_s)
         hipLaunchKernelGGL((k_joint_fwd<true, false>), grid, block, 0, st, a);
     else
