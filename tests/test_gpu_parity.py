@@ -436,3 +436,23 @@ def test_fullsize_config5_bf16_vs_fp32(amd):
     """Large vocabulary (B=16,T=800,U=150,H=512,V=16384) on the bf16 route: 64 forward passes, 512
     k chunks per dHidden tile, 64 dW column tiles."""
     _bf16_vs_fp32_fullsize(amd, 16, 800, 150, 512, 16384, seed=35)
+
+
+def test_fullsize_config2_softmax_shift_invariance(amd):
+    """Size-independent property at BASELINE config 2's full size with random W: adding a constant
+    to every bias entry shifts all logits of a cell equally, so costs and every gradient must not
+    move (the bias gradient keeps summing to ~0 as well).  Exercises all kernels on dense,
+    non-degenerate data at 6.4 M cells."""
+    d = make_inputs(32, 1000, 200, 512, 1024, seed=77)
+    amd.engine.release_workspaces()
+    r0 = _run_fused(amd, d)
+    d2 = dict(d)
+    d2["bias"] = (d["bias"] + np.float32(2.5)).astype(np.float32)
+    r1 = _run_fused(amd, d2)
+    amd.engine.release_workspaces()
+    assert_close_loss("costs", r1["costs"], r0["costs"], rtol=2e-5)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r1[k], r0[k], rtol=2e-4)
+    assert abs(r0["grad_bias"].sum()) < 1e-3 * np.abs(r0["grad_bias"]).sum()
+    # per-utterance costs of ragged full-size inputs are positive and ordered by lattice size
+    assert (r0["costs"] > 0).all()

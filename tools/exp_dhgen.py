@@ -16,8 +16,7 @@ def timeit(stage, n=3):
     for _ in range(n): run(stage)
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n
-for flags, name in ((0, "normal"), (256, "no G stores"), (4096, "no logits loads"), (8192, "no epilogue"),
-                    (256 + 4096, "no stores/loads"), (256 + 4096 + 8192, "no stores/loads/epilogue")):
+for flags, name in ((0, "normal"), (8192, "no epilogue")):
     engine.lib().rnnt_engine_set_flags(flags)
     print(f"dhidden_gen {name:26s}: {timeit(4):.2f} ms", flush=True)
 engine.lib().rnnt_engine_set_flags(0)
