@@ -1,0 +1,43 @@
+"""CPU test: the bench line committed under profiles/ (produced by `python bench.py` on an MI355X)
+carries every field the bench contract names, with consistent values."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    text = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
+    return json.loads(text)
+
+
+def _check(d, dtype):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "cells/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "strong" and d["data"] == "synthetic" and d["dtype"] == dtype and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    B, T, U = 32, 1000, 200  # BASELINE configs[1]
+    assert abs(d["value"] - B * T * U / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == "cells/s" and c["cores"] >= 1
+
+
+def test_committed_fp32_bench_line():
+    d = _line("r01_bench_default.json")
+    _check(d, "f32")
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 157.3
+
+
+def test_committed_bf16_bench_line():
+    d = _line("r01_bf16_bench_default.json")
+    _check(d, "bf16")
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
