@@ -214,8 +214,16 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     const bool fuse_g = dhidden_gen_ok(H, V) && !(g_flags & 32);
     if (fuse_g) g.flags |= 16;
 
+    // hidden (A operand of all three GEMMs) is produced by the forward kernel for its own tile
+    // unless flag 64 asks for the separate k_make_hidden pass
+    const bool fuse_hid = !(g_flags & 64) && !(g_flags & 8);
     if (stages & ST_PROD) {
-        launch_make_hidden(g, st);  // A operand of the forward GEMM and of both backward GEMMs
+        if (fuse_hid) {  // only the zero padding rows the dW GEMM walks past the last cell
+            const size_t cells = (size_t)B * T * U1;
+            (void)hipMemsetAsync(g.hidden + cells * H, 0, (L.rows_pad + 16 - cells) * H * 4, st);
+        } else {
+            launch_make_hidden(g, st);
+        }
         launch_pack_w_fwd((const float *)W, wpack, H, V, st);
     }
     if (stages & ST_FWD) {
@@ -225,6 +233,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         f.logit_lens = logit_lens; f.target_lens = target_lens; f.logits = logits;
         f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
         f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = g_flags; f.debug = g_debug;
+        f.make_hidden = fuse_hid ? 1 : 0;
         launch_joint_fwd(f, st);
     }
     if (stages & ST_LATTICE)

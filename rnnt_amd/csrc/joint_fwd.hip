@@ -302,7 +302,7 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
 #define STAMP(slot)
 #endif
 
-template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false>
+template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false, bool MAKE_HID = false>
 __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
 {
     // ALL LDS in one array (hipcc otherwise guards every ds_read with vmcnt(0) while an LDS-DMA
@@ -324,6 +324,40 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int Tb = WITH_LOSS ? a.logit_lens[b] : T;
     const int ncell = Tb * U1;
+    if (MAKE_HID) {
+        // hidden = tanh(enc + pred) for this tile's cells, produced here instead of by a separate
+        // 13 GB pass (k_make_hidden): ~1 % of the tile's time, and the main loop's loads of it hit
+        // L2.  EVERY cell of the utterance gets a finite row, also past its length: the backward
+        // GEMMs multiply those rows by exact zeros.
+        // Wave w takes rows w, w+8, ...; a lane takes 4 consecutive h.  All loads of a batch of 8
+        // rows are issued before the first tanh so a tile pays ~4 memory round trips, not 32.
+        const int nrow = T * U1 - m0 < FWD_ROWS ? T * U1 - m0 : FWD_ROWS;
+        float *hid = (float *)a.hidden + ((long)b * T * U1 + m0) * H;
+        const float *encb = a.enc + (long)b * a.enc_sb, *predb = a.pred + (long)b * U1 * H;
+        constexpr int NW = FWD_THREADS / 64, BATCH = 8;
+        for (int h = (tid & 63) * 4; h < H; h += 256) {
+            for (int rb = 0; rb < FWD_ROWS / NW; rb += BATCH) {
+                f32x4 e[BATCH], p[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int r = wave + (rb + i) * NW;
+                    const int c = m0 + (r < nrow ? r : nrow - 1);  // clamped: loads stay unconditional
+                    const int t = c / U1, u = c - t * U1;
+                    e[i] = *(const f32x4 *)(encb + (long)t * a.enc_st + h);
+                    p[i] = *(const f32x4 *)(predb + (long)u * H + h);
+                }
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int r = wave + (rb + i) * NW;
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[i][q] + p[i][q]);
+                    if (r < nrow) *(f32x4 *)(hid + (long)r * H + h) = o;
+                }
+            }
+        }
+        __syncthreads();  // stores acknowledged (vmcnt(0)) and every wave past them
+    }
     if (m0 >= ncell) return;
     STAMP(0);
 #ifdef RNNT_STAMPS
@@ -486,12 +520,13 @@ void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
 {
     const int tiles = (int)(((long)a.T * a.U1 + FWD_ROWS - 1) / FWD_ROWS);
     dim3 grid(tiles, a.B), block(FWD_THREADS);
-    if (a.denom_s && a.hidden)
-        if (((a.H + 7) / 8) % 2 == 0)  // even number of 8-wide chunks: the two-register-set main loop
-            hipLaunchKernelGGL((k_joint_fwd<true, true, true>), grid, block, 0, st, a);
-        else
-            hipLaunchKernelGGL((k_joint_fwd<true, true>), grid, block, 0, st, a);
-    else if (a.denom_s)
+    if (a.denom_s && a.hidden) {
+        const bool pairs = ((a.H + 7) / 8) % 2 == 0;  // even number of 8-wide chunks: the two-register-set main loop
+        if (a.make_hidden && pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true, true>), grid, block, 0, st, a);
+        else if (a.make_hidden) hipLaunchKernelGGL((k_joint_fwd<true, true, false, true>), grid, block, 0, st, a);
+        else if (pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_joint_fwd<true, true>), grid, block, 0, st, a);
+    } else if (a.denom_s)
         hipLaunchKernelGGL((k_joint_fwd<true, false>), grid, block, 0, st, a);
     else
         hipLaunchKernelGGL((k_joint_fwd<false, false>), grid, block, 0, st, a);

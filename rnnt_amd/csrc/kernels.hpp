@@ -23,7 +23,8 @@ struct JointFwdArgs {
     long enc_sb, enc_st;
     const float *pred;  // [B,U1,H] contiguous
     const float *wpack; // packed W (pack_w_fwd)
-    const float *hidden; // [rows,H] tanh(enc+pred) from k_make_hidden (fused path), else NULL
+    const float *hidden; // [rows,H] tanh(enc+pred) (fused path), else NULL
+    int make_hidden;     // 1: the forward kernel itself fills `hidden` for its tile (no k_make_hidden pass)
     const float *bias;  // [V]
     const int32_t *targets, *logit_lens, *target_lens;  // all NULL for the plain joint
     float *logits;      // [B,T,U1,V]
