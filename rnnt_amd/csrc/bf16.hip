@@ -55,32 +55,52 @@ __device__ __forceinline__ void lds_barrier()
 // ---------------------------------------------------------------------------------------
 // producers
 // ---------------------------------------------------------------------------------------
-// hidden[c,:] = bf16(tanh(enc[b,t,:] + pred[b,u,:])), zero rows for c >= cells (row padding)
+// hidden[c,:] = bf16(tanh(enc[b,t,:] + pred[b,u,:])), zero rows for c >= cells (row padding).
+// A thread owns 8 columns (16 B of bf16) of HID_R consecutive cells: they share their enc row
+// unless the run crosses a t boundary, so the kernel issues ~2.5 loads per 16-byte store
+// instead of 4 (it is bound by load/store issue, not by HBM: 6.6 GB written).
+#define HID_R 4
 __global__ __launch_bounds__(256) void k_make_hidden_bf16(const float *__restrict__ enc, long sb,
                                                           long st_, const float *__restrict__ pred,
                                                           u32x4 *__restrict__ hid, int B, int T,
                                                           int U1, int H, long rows)
 {
-    const int H8 = H / 8;  // 8 columns (16 B of bf16) per thread
+    const int H8 = H / 8;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * H8) return;
-    const long c = idx / H8;
-    const int h = (int)(idx - c * H8) * 8;
-    u32x4 o = {0u, 0u, 0u, 0u};
-    if (c < (long)B * T * U1) {
-        const int u = (int)(c % U1);
-        const long bt = c / U1;
-        const int t = (int)(bt % T), b = (int)(bt / T);
-        const float *ep = enc + (long)b * sb + (long)t * st_ + h;
-        const float *pp = pred + ((long)b * U1 + u) * H + h;
-        const f32x4 e0 = *(const f32x4 *)ep, e1 = *(const f32x4 *)(ep + 4);
-        const f32x4 p0 = *(const f32x4 *)pp, p1 = *(const f32x4 *)(pp + 4);
-        o[0] = pack_bf16(fast_tanh(e0[0] + p0[0]), fast_tanh(e0[1] + p0[1]));
-        o[1] = pack_bf16(fast_tanh(e0[2] + p0[2]), fast_tanh(e0[3] + p0[3]));
-        o[2] = pack_bf16(fast_tanh(e1[0] + p1[0]), fast_tanh(e1[1] + p1[1]));
-        o[3] = pack_bf16(fast_tanh(e1[2] + p1[2]), fast_tanh(e1[3] + p1[3]));
+    const long grp = idx / H8;  // run of HID_R cells
+    const int h = (int)(idx - grp * H8) * 8;
+    const long c0 = grp * HID_R;
+    if (c0 >= rows) return;
+    const long cells = (long)B * T * U1;
+    int u = (int)(c0 % U1);
+    const long bt0 = c0 / U1;
+    int t = (int)(bt0 % T), b = (int)(bt0 / T);  // carried along the run: no further divisions
+    f32x4 e0, e1;
+    bool have_e = false;
+#pragma unroll
+    for (int i = 0; i < HID_R; ++i) {
+        const long c = c0 + i;
+        if (c >= rows) break;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (c < cells) {
+            if (!have_e) {
+                const float *ep = enc + (long)b * sb + (long)t * st_ + h;
+                e0 = *(const f32x4 *)ep; e1 = *(const f32x4 *)(ep + 4);
+                have_e = true;
+            }
+            const float *pp = pred + ((long)b * U1 + u) * H + h;
+            const f32x4 p0 = *(const f32x4 *)pp, p1 = *(const f32x4 *)(pp + 4);
+            o[0] = pack_bf16(fast_tanh(e0[0] + p0[0]), fast_tanh(e0[1] + p0[1]));
+            o[1] = pack_bf16(fast_tanh(e0[2] + p0[2]), fast_tanh(e0[3] + p0[3]));
+            o[2] = pack_bf16(fast_tanh(e1[0] + p1[0]), fast_tanh(e1[1] + p1[1]));
+            o[3] = pack_bf16(fast_tanh(e1[2] + p1[2]), fast_tanh(e1[3] + p1[3]));
+        }
+        hid[c * H8 + h / 8] = o;
+        if (++u == U1) {  // next cell starts a new enc row
+            u = 0; have_e = false;
+            if (++t == T) { t = 0; ++b; }
+        }
     }
-    hid[idx] = o;
 }
 
 // forward B operand, fragment order: [pass][c][s][tile(8)][lane] x 8 bf16,
@@ -131,7 +151,7 @@ size_t bf16_wpack_dh_bytes(int V) { return (size_t)(V / 32) * 2 * 16 * 64 * 16; 
 
 void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
 {
-    const long nh = a.rows_alloc * (a.H / 8);
+    const long nh = (a.rows_alloc + HID_R - 1) / HID_R * (a.H / 8);
     hipLaunchKernelGGL(k_make_hidden_bf16, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
                        a.enc, a.enc_sb, a.enc_st, a.pred, (u32x4 *)a.hidden, a.B, a.T, a.U1, a.H,
                        a.rows_alloc);
@@ -434,8 +454,22 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
         }
         const u32x4 o = {pack_bf16(g[0], g[1]), pack_bf16(g[2], g[3]), pack_bf16(g[4], g[5]), pack_bf16(g[6], g[7])};
         s_g[slot * 512 + gdst] = o;
-        if (pexists && c < VC && !RNNT_XP(a.flags, 256)) grow[4 * c] = o;
     };
+    // G goes to memory in PAIRS of chunks, read back from this wave's own part of the exchange in
+    // row-major order: lane (row = 8i + (l>>3), piece = l&7) stores 16 B, so a store instruction
+    // writes 8 whole 128-byte lines (the producer layout — 4 lanes per row — wrote 16 half lines
+    // per instruction and was bound by store issue).  Pair (c-1, c), c odd: both chunks sit in
+    // the two exchange slots between the production of c and that of c+1.
+    const int sp = lane & 7, sr = lane >> 3;  // piece: chunk parity sp>>2, quarter sp&3
+    const int gsrc = (sp >> 2) * 512 + (wave >> 1) * 128 + (sp & 1) * 64 + ((sp >> 1) & 1) * 32 + 16 * (wave & 1) + sr;
+    u32x4 *gst[2];
+    bool gst_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int su = u0 + 8 * i + sr;
+        gst_ok[i] = pt < T && su < U1;
+        gst[i] = (u32x4 *)(a.logits + (gst_ok[i] ? ((long)b * T + pt) * U1 + su : zrow) * V) + sp;
+    }
     auto wload = [&](u32x4 (&w)[4], int c) {
         const u32x4 *p = wp + (long)(c < VC ? c : VC - 1) * 2048;
 #pragma unroll
@@ -472,6 +506,11 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
             // G of chunk c+1 (logits requested 4 chunks ago) into the other exchange slot
             produce(xr[(q + 1) & 3][0], xr[(q + 1) & 3][1], c + 1, (q + 1) & 1);
             xload(xr[(q + 1) & 3], c + 5);
+            u32x4 gb[2];
+            if (!(q & 1)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
+                gb[0] = s_g[gsrc];
+                gb[1] = s_g[gsrc + 8];
+            }
             __builtin_amdgcn_sched_barrier(0);
             {
                 const u32x4 a0 = s_g[(q & 1) * 512 + wm * 128 + lane];
@@ -494,6 +533,10 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
+            }
+            if (!(q & 1) && !RNNT_XP(a.flags, 256)) {
+                if (gst_ok[0]) gst[0][4 * c] = gb[0];
+                if (gst_ok[1]) gst[1][4 * c] = gb[1];
             }
             lds_barrier();
         }
