@@ -234,8 +234,8 @@ def main():
                            "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
         if args.dtype == "bf16":
             # 16x the matrix rate: every kernel of this route is HBM-bound.  Algorithmic bytes per
-            # cell (rnnt_amd/csrc/bf16.hip header): fwd 2H+4V, dHidden 4V+2V+2H, dW 2V+2H
-            per_cell = {"joint_fwd_gemm": 2 * H + 4 * V, "dhidden_gemm": 6 * V + 2 * H, "dw_gemm": 2 * V + 2 * H}
+            # cell (rnnt_amd/csrc/bf16.hip header; logits stored fp16): fwd 2H+2V, dHidden 2V+2V+2H, dW 2V+2H
+            per_cell = {"joint_fwd_gemm": 2 * H + 2 * V, "dhidden_gemm": 4 * V + 2 * H, "dw_gemm": 2 * V + 2 * H}
             gbs = per_cell[dom] * cells1 / (gemms[dom] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,

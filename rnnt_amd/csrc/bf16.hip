@@ -5,18 +5,23 @@
 // bf16 (round-to-nearest-even) and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation — 16x the fp32 matrix rate, so this route is HBM-bound:
 //   hidden = bf16(tanh(enc+pred))        k_make_hidden_bf16      writes  2H  B/cell
-//   logits = hidden . bf16(W)^T + b      k_joint_fwd_bf16        reads 2H, writes 4V B/cell
+//   logits = f16(hidden . bf16(W)^T + b) k_joint_fwd_bf16        reads 2H, writes 2V B/cell
 //   softmax statistics, lattice, coef    fp32 / fp64, shared with the fp32 route (lattice.hip)
-//   G = bf16(exp2(logit*log2e+c1) - ..)  k_dhidden_bf16          reads 4V+2H, writes 2V B/cell
+//   G = bf16(exp2(logit*log2e+c1) - ..)  k_dhidden_bf16          reads 2V+2H, writes 2V B/cell
 //   dHidden = G . bf16(W), x(1-h^2), sums                        (same kernel)
 //   dW = G^T . hidden, db = colsum(G)    k_dw_bf16               reads 2V+2H B/cell
-// Logits stay fp32 (the loss needs them); G overwrites the first half of its logits row.
+// The logits are STORED in fp16 (round-to-nearest-even; half the bytes of the two kernels that
+// stream them) and everything downstream — softmax statistics, the blank/label log-probs, G —
+// is computed from the stored values, so the route is exactly "fp16 logits": the accumulators
+// are fp32, |logit| stays far below the fp16 range (hidden is in [-1,1]), and the rounding
+// (2^-11 relative) is below the bf16 rounding of G it feeds.  G (bf16) overwrites its logits
+// row in place, byte for byte.
 //
 // MFMA operand maps (cdna_hip_programming.md §3): lane l = (r = l&31, h = l>>5) holds
 // A[row r][k = 8h+j] and B[k = 8h+j][col r], j = 0..7; C/D: col = l&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Two conventions used throughout:
 //  * K permutation: a 32-wide k chunk is consumed by 2 MFMAs; the lane's 16 consecutive k
-//    (32 contiguous bytes of bf16, or 64 of fp32 logits) feed MFMA s=0 with its first 8 and
+//    (32 contiguous bytes of bf16 or fp16) feed MFMA s=0 with its first 8 and
 //    MFMA s=1 with its last 8: MFMA s, slot (h,j)  <->  k = 32c + 16h + 8s + j.  Both operands
 //    use the same map, so the dot product is unchanged and every global access is >= 32 B/lane.
 //  * Column interleave by 4: accumulator tile 4g+q holds columns 128g + 4*(l&31) + q, so a
@@ -35,6 +40,15 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
     bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
     return __builtin_bit_cast(unsigned, v);
 }
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ unsigned pack_f16(float lo, float hi)
+{
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));  // v_cvt_pk_f16_f32 (RNE)
+}
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c)
@@ -104,7 +118,9 @@ __global__ __launch_bounds__(256) void k_make_hidden_bf16(const float *__restric
 }
 
 // forward B operand, fragment order: [pass][c][s][tile(8)][lane] x 8 bf16,
-// element j = W[v = 256*pass + 128*(tile>>2) + 4*(lane&31) + (tile&3)][h = 32c + 16*(lane>>5) + 8s + j]
+// element j = W[v = 256*pass + 8*(lane&31) + tile][h = 32c + 16*(lane>>5) + 8s + j]
+// (columns interleaved by 8 here: a lane's 8 accumulator tiles are 8 adjacent logits = one
+// 16-byte fp16 store)
 __global__ __launch_bounds__(256) void k_pack_w_fwd_bf16(const float *__restrict__ W,
                                                          u32x4 *__restrict__ out, int H, int V,
                                                          int KC, long n)
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256) void k_pack_w_fwd_bf16(const float *__restrict
     const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 7, s = (int)(idx >> 9) & 1;
     const long cc = idx >> 10;
     const int c = (int)(cc % KC), pass = (int)(cc / KC);
-    const int v = 256 * pass + 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
+    const int v = 256 * pass + 8 * (lane & 31) + tile;
     const int h0 = 32 * c + 16 * (lane >> 5) + 8 * s;
     u32x4 o = {0u, 0u, 0u, 0u};
     if (v < V) {
@@ -212,7 +228,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], u32x4 a0, u32x4 a1,
 }
 
 // ---------------------------------------------------------------------------------------
-// k_joint_fwd_bf16: logits[c, :] = hidden[c, :] . W^T + bias   (fp32 out)
+// k_joint_fwd_bf16: logits[c, :] = f16(hidden[c, :] . W^T + bias)
 // grid = rows_alloc/128 workgroups of 256 threads, 2 per CU (128 accumulator registers);
 // pass = 256 columns (8 tiles), chunks run linearly over (pass, c): the staging pipeline
 // never drains at a pass boundary.  A fragments: 32 B per lane per chunk straight from the
@@ -272,27 +288,22 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
             __builtin_amdgcn_sched_barrier(0);
             if (!RNNT_XP(a.flags, 1024)) mma_chunk<NT, 5>(acc, ar[q][0], ar[q][1], s_b[q & 1], lane);
             if (q == 3 && c + 4 == KC) {  // pass complete (KC % 4 == 0): bias, store, softmax statistics
-                const bool g1 = 256 * pass + 128 < V;  // V % 128 == 0: a 128-column group is all in or out
-                const int col0 = 256 * pass + 4 * j;
-                const f32x4 b0 = *(const f32x4 *)(a.bias + col0);
-                const f32x4 b1 = *(const f32x4 *)(a.bias + (g1 ? col0 + 128 : col0));
+                const int col0 = 256 * pass + 8 * j;  // this lane's 8 adjacent columns
+                const bool cok = col0 < V;            // V % 128 == 0: the last pass may be half empty
+                const f32x4 b0 = *(const f32x4 *)(a.bias + (cok ? col0 : 0));
+                const f32x4 b1 = *(const f32x4 *)(a.bias + (cok ? col0 + 4 : 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const f32x4 o0 = {acc[0][r] + b0[0], acc[1][r] + b0[1], acc[2][r] + b0[2], acc[3][r] + b0[3]};
-                    f32x4 o1 = {acc[4][r] + b1[0], acc[5][r] + b1[1], acc[6][r] + b1[2], acc[7][r] + b1[3]};
-                    if (!RNNT_XP(a.flags, 256)) {
-                        if (!RNNT_XP(a.flags, 1)) {  // streaming stores: the logits are not re-read by this kernel's CUs
-                                              // and should not evict the A rows the next pass re-reads from L2
-                            __builtin_nontemporal_store(o0, (f32x4 *)(a.logits + orow * V + col0));
-                            if (g1) __builtin_nontemporal_store(o1, (f32x4 *)(a.logits + orow * V + col0 + 128));
-                        } else {
-                            *(f32x4 *)(a.logits + orow * V + col0) = o0;
-                            if (g1) *(f32x4 *)(a.logits + orow * V + col0 + 128) = o1;
-                        }
-                    }
-                    if (!g1) o1 = o0;  // duplicates only feed the max; their exp terms are dropped below
-                    if (RNNT_XP(a.flags, 512)) continue;
+                    // fp16 logits: round, store, and take the statistics from the rounded values
+                    const u32x4 qv = {pack_f16(acc[0][r] + b0[0], acc[1][r] + b0[1]), pack_f16(acc[2][r] + b0[2], acc[3][r] + b0[3]),
+                                      pack_f16(acc[4][r] + b1[0], acc[5][r] + b1[1]), pack_f16(acc[6][r] + b1[2], acc[7][r] + b1[3])};
+                    // streaming stores: the logits are not re-read by this kernel's CUs and should
+                    // not evict the A rows the next pass re-reads from L2
+                    if (cok && !RNNT_XP(a.flags, 256)) __builtin_nontemporal_store(qv, (u32x4 *)(a.logits + orow * V + col0));
+                    const f32x4 o0 = {f16_lo(qv[0]), f16_hi(qv[0]), f16_lo(qv[1]), f16_hi(qv[1])};
+                    const f32x4 o1 = {f16_lo(qv[2]), f16_hi(qv[2]), f16_lo(qv[3]), f16_hi(qv[3])};
+                    if (RNNT_XP(a.flags, 512) || !cok) continue;  // columns past V (zero weights) are no logits
                     // running (max, sum exp) of this lane's columns of row-slot r
                     const float lmax = fmaxf(fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3])),
                                              fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
@@ -304,8 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
                           __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
                          (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) +
                           __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
-                    if (g1)
-                        e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) +
+                    e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) +
                               __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
                              (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) +
                               __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
@@ -345,17 +355,21 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         const int Ub = a.target_lens[b];
         if (t < a.logit_lens[b] && u <= Ub) {
             const float den = s_den[wave * 32 + j];
-            const float *lrow = a.logits + cell * V;
+            const unsigned short *lrow = a.logits + cell * V;
             const long si = skew_index(b, t, u, a.D, U1);
+            auto stored = [&](int v) {  // fp16 logit v of this row, read through L2
+                const unsigned w = __hip_atomic_load((const unsigned *)(lrow + (v & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return (v & 1) ? f16_hi(w) : f16_lo(w);
+            };
             if (half == 0) {
-                const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float lb = stored(a.blank);
                 a.denom_s[si] = den;
                 a.lpb_s[si] = lb - den;
             } else {
                 float le = 0.f;
                 if (u < Ub) {
                     const int y = a.targets[(long)b * (U1 - 1) + u];
-                    le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                    le = stored(y) - den;
                 }
                 a.lpe_s[si] = le;
             }
@@ -369,17 +383,20 @@ void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------
-// k_dhidden_bf16: G from logits, stored as bf16 over the first half of its logits row, and
+// k_dhidden_bf16: G from the fp16 logits, stored as bf16 over its logits row (in place), and
 // dHidden = G . W over all H <= 512 columns; epilogue as the fp32 kernel: x (1 - hidden^2),
 // sum over u -> dEnc slab, sum over t -> dPred slab.  Tile = 8 t x 16 u cells.
 // 8 waves (two per SIMD, 128 accumulator registers each):
 //  * production: wave w turns t-row w of the tile into G: lane (u = l&15, quarter = l>>4) owns
-//    8 consecutive vocabulary entries per 32-wide chunk (32 B of logits in, 16 B of bf16 out: a
-//    row's four lanes cover its whole 128-B line), one chunk ahead of the MFMAs, and drops its
+//    8 consecutive vocabulary entries per 32-wide chunk (16 B of fp16 logits in, 16 B of bf16
+//    out, same bytes), one chunk ahead of the MFMAs, and drops its
 //    16 B straight into the MFMA A-fragment image of its M-tile in LDS (double-buffered);
-//  * consumption: wave (wm = w&3, wn = w>>2) multiplies M-tile wm (t-rows 2wm, 2wm+1) by the
-//    column half wn (8 tiles); A fragments from the exchange, B fragments from the staged W
-//    chunk (each wave copies 4 KiB of it L2 -> VGPR -> LDS two chunks ahead).
+//  * consumption: wave (wm = w&1, wn = w>>1) multiplies M-tiles 2wm, 2wm+1 (t-rows 4wm..4wm+3) by
+//    the 128-column group wn (4 tiles): every B fragment it reads feeds two MFMAs.  The loop is
+//    bound by LDS bandwidth (with everything but the exchange switched off it still took 8.4 of
+//    12 ms): a 32-row x 256-column wave tile needs 18 fragment reads per 16 MFMAs, this one 12.
+//    A fragments from the exchange, B fragments from the staged W chunk (each wave copies
+//    4 KiB of it L2 -> VGPR -> LDS two chunks ahead).
 // One barrier per chunk publishes both.  grid (n_ublk, ceil(T/8), B), 512 threads.
 // Requires V % 128 == 0, H % 128 == 0, H <= 512.
 // ---------------------------------------------------------------------------------------
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     u32x4 *s_b = s_mem, *s_g = s_mem + 2 * 2048;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave & 1, wn = wave >> 1;
     const int j = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     const bool pexists = pt < T && pu < U1;
     const long zrow = (long)a.B * T * U1;  // first zero padding row
     const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : zrow;
-    float *lrow = a.logits + pcell * V;
+    unsigned short *lrow = a.logits + pcell * V;
     u32x4 *grow = (u32x4 *)lrow + qd;  // chunk c: grow[4c]  (16 B of bf16 at byte 64c + 16qd)
 
     if (t0 >= Tb) {  // workgroup-uniform: no products, but k_dw_bf16 must find zeros here
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
     if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
     // rows outside the lattice read the zero padding row (finite) with c1 = -inf -> G = 0
-    const f32x4 *xsrc = (const f32x4 *)(live ? lrow : a.logits + zrow * V) + 2 * qd;  // chunk c: xsrc[8c], xsrc[8c+1]
+    const u32x4 *xsrc = (const u32x4 *)(live ? lrow : a.logits + zrow * V) + qd;  // chunk c: xsrc[4c]
     const int blank = a.blank;
     // fragment image: MFMA s, lane (r, h) holds k = 16h + 8s + 0..7 of the chunk = quarter 2h + s
     // -> this lane's 16 B go to [M-tile wave>>1][s = qd&1][lane (qd>>1)*32 + 16*(wave&1) + r16]
@@ -435,12 +452,12 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
 
-    auto produce = [&](const f32x4 &x0, const f32x4 &x1, int c, int slot) {
+    auto produce = [&](const u32x4 &x, int c, int slot) {
         float g[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            g[e] = __builtin_amdgcn_exp2f(fmaf(x0[e], RNNT_LOG2E, cf.c1));
-            g[4 + e] = __builtin_amdgcn_exp2f(fmaf(x1[e], RNNT_LOG2E, cf.c1));
+            g[2 * e] = __builtin_amdgcn_exp2f(fmaf(f16_lo(x[e]), RNNT_LOG2E, cf.c1));
+            g[2 * e + 1] = __builtin_amdgcn_exp2f(fmaf(f16_hi(x[e]), RNNT_LOG2E, cf.c1));
         }
         const int vb = 32 * c + 8 * qd;
         const unsigned dy = (unsigned)(cf.y - vb);
@@ -480,20 +497,16 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[i * 64] = w[i];
     };
-    auto xload = [&](f32x4 (&x)[2], int c) {
-        const int cc = c < VC ? c : VC - 1;
-        x[0] = xsrc[8 * cc];
-        x[1] = xsrc[8 * cc + 1];
-    };
+    auto xload = [&](u32x4 &x, int c) { x = xsrc[4 * (c < VC ? c : VC - 1)]; };
 
-    f32x4 xr[4][2];  // logits ring (slot = chunk & 3), 4 chunks ahead of production
+    u32x4 xr[4];  // logits ring (slot = chunk & 3), 4 chunks ahead of production
     u32x4 wx[4], wy[4];  // staged W: even / odd chunks
     xload(xr[0], 0); xload(xr[1], 1); xload(xr[2], 2); xload(xr[3], 3);
     wload(wx, 0);
     wload(wy, 1);
     wstore(wx, 0);
     wload(wx, 2);
-    produce(xr[0][0], xr[0][1], 0, 0);
+    produce(xr[0], 0, 0);
     xload(xr[0], 4);
     lds_barrier();
 
@@ -504,49 +517,52 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
             if (q & 1) { wstore(wx, 0); wload(wx, c + 3); }
             else       { wstore(wy, 1); wload(wy, c + 3); }
             // G of chunk c+1 (logits requested 4 chunks ago) into the other exchange slot
-            produce(xr[(q + 1) & 3][0], xr[(q + 1) & 3][1], c + 1, (q + 1) & 1);
+            produce(xr[(q + 1) & 3], c + 1, (q + 1) & 1);
             xload(xr[(q + 1) & 3], c + 5);
-            u32x4 gb[2];
-            if (!(q & 1)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
-                gb[0] = s_g[gsrc];
-                gb[1] = s_g[gsrc + 8];
-            }
             __builtin_amdgcn_sched_barrier(0);
             {
-                const u32x4 a0 = s_g[(q & 1) * 512 + wm * 128 + lane];
-                const u32x4 a1 = s_g[(q & 1) * 512 + wm * 128 + 64 + lane];
-                // this wave's 8 column tiles of the staged chunk: tiles 8wn .. 8wn+7 of each s
-                const u32x4 *pb = s_b + (q & 1) * 2048 + (8 * wn) * 64 + lane;
-                constexpr int DEPTH = 4;
+                u32x4 af[2][2];  // [M-tile][k-step]
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_) af[mt][s_] = s_g[(q & 1) * 512 + (2 * wm + mt) * 128 + s_ * 64 + lane];
+                // this wave's 4 column tiles of the staged chunk: tiles 4wn .. 4wn+3 of each k-step
+                const u32x4 *pb = s_b + (q & 1) * 2048 + (4 * wn) * 64 + lane;
+                constexpr int DEPTH = 3;
                 u32x4 bf[DEPTH + 1];
 #pragma unroll
-                for (int i = 0; i < DEPTH; ++i) bf[i] = pb[((i >> 3) * 16 + (i & 7)) * 64];
+                for (int n = 0; n < DEPTH; ++n) bf[n] = pb[((n >> 2) * 16 + (n & 3)) * 64];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (i + DEPTH < 16) bf[(i + DEPTH) % (DEPTH + 1)] = pb[(((i + DEPTH) >> 3) * 16 + ((i + DEPTH) & 7)) * 64];
-                    acc[i & 7] = mfma_bf16(i < 8 ? a0 : a1, bf[i % (DEPTH + 1)], acc[i & 7]);
+                for (int n = 0; n < 8; ++n) {
+                    if (n + DEPTH < 8) bf[(n + DEPTH) % (DEPTH + 1)] = pb[(((n + DEPTH) >> 2) * 16 + ((n + DEPTH) & 3)) * 64];
+                    acc[n & 3] = mfma_bf16(af[0][n >> 2], bf[n % (DEPTH + 1)], acc[n & 3]);
+                    acc[4 + (n & 3)] = mfma_bf16(af[1][n >> 2], bf[n % (DEPTH + 1)], acc[4 + (n & 3)]);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, DEPTH + 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + DEPTH + 2, 0);
 #pragma unroll
-                for (int i = 0; i < 16 - DEPTH; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                for (int n = 0; n < 8 - DEPTH; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * DEPTH, 0);
             }
-            if (!(q & 1) && !RNNT_XP(a.flags, 256)) {
-                if (gst_ok[0]) gst[0][4 * c] = gb[0];
-                if (gst_ok[1]) gst[1][4 * c] = gb[1];
+            if (!(q & 1) && !RNNT_XP(a.flags, 256)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 gb0 = s_g[gsrc], gb1 = s_g[gsrc + 8];
+                if (gst_ok[0]) gst[0][4 * c] = gb0;
+                if (gst_ok[1]) gst[1][4 * c] = gb1;
             }
             lds_barrier();
         }
     }
 
-    // ---- epilogue.  Accumulator register r of tile 4g+q (g = 0,1): row (r&3) + 8(r>>2) + 4*half
-    // of M-tile wm = (t-row 2wm + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 256wn + 128g + 4j + q.
+    // ---- epilogue.  Accumulator register r of tile 4mt+q (mt = 0,1): row (r&3) + 8(r>>2) + 4*half
+    // of M-tile 2wm+mt = (t-row 2(2wm+mt) + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 128wn + 4j + q.
     if (RNNT_XP(a.flags, 8192)) return;
     float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+    const int col0 = 128 * wn + 4 * j;
+    const bool colok = col0 < H;
     // All 32 hidden fragments of the epilogue requested up front through a raw buffer over the
     // tile's rows (scalar row offset + per-lane offset, no predicates: one memory round trip
     // instead of four; rows outside the lattice have G = 0 and therefore an exactly zero
@@ -558,40 +574,36 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
         const long span = (long)(BG_BT - 1) * U1 + BG_BU < rows_left ? (long)(BG_BT - 1) * U1 + BG_BU : rows_left;
         const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.hidden + cell0 * H), 0, (int)(span * H * 2), 0x00020000);
+        const unsigned voff = colok ? (unsigned)(((4 * half) * H + col0) * 2) : 0xfffffff0u;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int col0 = 256 * wn + 128 * g + 4 * j;
-            const unsigned voff = col0 < H ? (unsigned)(((4 * half) * H + col0) * 2) : 0xfffffff0u;
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int tl_ = 0; tl_ < 2; ++tl_)
 #pragma unroll
                 for (int r7 = 0; r7 < 8; ++r7) {
-                    const unsigned soff = (unsigned)(((2 * wm + tl_) * U1 + (r7 & 3) + 8 * (r7 >> 2)) * H) * 2u;
-                    hq[g][tl_][r7] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, voff, soff, 0));
+                    const unsigned soff = (unsigned)(((2 * (2 * wm + mt) + tl_) * U1 + (r7 & 3) + 8 * (r7 >> 2)) * H) * 2u;
+                    hq[mt][tl_][r7] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(hrsrc, voff, soff, 0));
                 }
-        }
     }
+    float psum[8][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int col0 = 256 * wn + 128 * g + 4 * j;
-        const bool colok = col0 < H;
-        float psum[8][4];
+    for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
-        for (int r7 = 0; r7 < 8; ++r7)
+        for (int q = 0; q < 4; ++q) psum[r7][q] = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) psum[r7][q] = 0.f;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int tl_ = 0; tl_ < 2; ++tl_) {
-            const int t = t0 + 2 * wm + tl_;
+            const int t = t0 + 2 * (2 * wm + mt) + tl_;
             const bool tok = t < Tb;
             float esum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r7 = 0; r7 < 8; ++r7) {
-                const u32x2 h2 = hq[g][tl_][r7];
+                const u32x2 h2 = hq[mt][tl_][r7];
                 const float hv[4] = {bf16_lo(h2[0]), bf16_hi(h2[0]), bf16_lo(h2[1]), bf16_hi(h2[1])};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float av = acc[4 * g + q][tl_ * 8 + r7];
+                    const float av = acc[4 * mt + q][tl_ * 8 + r7];
                     const float d = av * (1.f - hv[q] * hv[q]);
                     esum[q] += d;
                     psum[r7][q] += d;
@@ -604,26 +616,24 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
                 *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + col0) = o;
             }
         }
-        __syncthreads();  // main loop / previous g done with the LDS being reused
+    __syncthreads();  // main loop done with the LDS being reused
 #pragma unroll
-        for (int r7 = 0; r7 < 8; ++r7)
+    for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s_red[(wave * 64 + lane) * 33 + r7 * 4 + q] = psum[r7][q];
-        __syncthreads();
-        // thread (wm, lane) of column half wn sums rows r7 = 2wm, 2wm+1 of source lane `lane`
-        // over the 4 waves (M-tiles) that share wn
+        for (int q = 0; q < 4; ++q) s_red[(wave * 64 + lane) * 33 + r7 * 4 + q] = psum[r7][q];
+    __syncthreads();
+    // thread (wm, lane) of column group wn sums rows r7 = 4wm .. 4wm+3 of source lane `lane` over
+    // the 2 waves (t-row quadruples) that share wn
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int r7 = 2 * wm + k;
-            const int u = u0 + (r7 & 3) + 8 * (r7 >> 2) + 4 * half;
-            if (u < U1 && colok) {
-                f32x4 o;
-                const float *sr = s_red + (wn * 4 * 64 + lane) * 33 + r7 * 4;
+    for (int k = 0; k < 4; ++k) {
+        const int r7 = 4 * wm + k;
+        const int u = u0 + (r7 & 3) + 8 * (r7 >> 2) + 4 * half;
+        if (u < U1 && colok) {
+            f32x4 o;
+            const float *sr = s_red + ((2 * wn) * 64 + lane) * 33 + r7 * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    o[q] = (sr[q] + sr[64 * 33 + q]) + (sr[2 * 64 * 33 + q] + sr[3 * 64 * 33 + q]);
-                *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + col0) = o;
-            }
+            for (int q = 0; q < 4; ++q) o[q] = sr[q] + sr[64 * 33 + q];
+            *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + col0) = o;
         }
     }
 }
@@ -632,7 +642,7 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
 {
     const long cells = (long)a.B * a.T * a.U1;
     // zero padding rows: G of rows k_dw_bf16 walks past the last cell, and the "dead row" source
-    (void)hipMemsetAsync(a.logits + cells * a.V, 0, (size_t)(a.rows_alloc - cells) * a.V * 4, st);
+    (void)hipMemsetAsync(a.logits + cells * a.V, 0, (size_t)(a.rows_alloc - cells) * a.V * 2, st);
     dim3 grid(a.n_ublk, (a.T + BG_BT - 1) / BG_BT, a.B);
     hipLaunchKernelGGL(k_dhidden_bf16, grid, dim3(512), 0, st, a);
 }
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         const bool is_g = wave < 2;
         int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
         if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
-        const long rstride = is_g ? 4L * V : 2L * H;  // bytes between cells (G sits in fp32 logits rows)
+        const long rstride = is_g ? 2L * V : 2L * H;  // bytes between cells
         const char *src = (is_g ? (const char *)a.logits : (const char *)a.hidden) +
                           (k_lo * BW_ROWS) * rstride + 2L * col0;
         // DMA i (0..7) of a stage: rows 4i .. 4i+3; lane L: row 4i + (L>>4), LDS chunk position L&15

@@ -75,7 +75,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     size_t o = 0;
     if (dtype == RNNT_DTYPE_BF16) {
         const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
-        L->logits = o;   o += align_up(ra * V * 4);
+        L->logits = o;   o += align_up(ra * V * 2);  // fp16
         L->hidden = o;   o += align_up(ra * H * 2);
     } else {
         L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
@@ -189,7 +189,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         h.W = (const float *)W; h.bias = (const float *)bias;
         h.hidden = (unsigned short *)(ws + L.hidden);
         h.wpack_fwd = ws + L.wpack; h.wpack_dh = ws + L.wpack + align_up(bf16_wpack_fwd_bytes(H, V));
-        h.logits = logits; h.coef = coef; h.logit_lens = logit_lens;
+        h.logits = (unsigned short *)logits; h.coef = coef; h.logit_lens = logit_lens;
         h.targets = targets; h.target_lens = target_lens;
         h.denom_s = denom_s; h.lpb_s = lpb_s; h.lpe_s = lpe_s; h.D = L.D;
         h.slab_enc = g.slab_enc; h.slab_pred = g.slab_pred; h.slab_w = g.slab_w; h.slab_b = g.slab_b;

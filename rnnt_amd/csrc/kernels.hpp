@@ -78,7 +78,7 @@ struct Bf16Args {
     const float *bias;
     unsigned short *hidden;  // bf16 [rows_alloc,H] tanh(enc+pred)
     void *wpack_fwd, *wpack_dh;
-    float *logits;       // fp32 [rows_alloc,V]; G (bf16) overwrites the first half of each row
+    unsigned short *logits;  // fp16 [rows_alloc,V]; G (bf16) overwrites each row in place
     const CellCoef *coef;
     const int32_t *targets, *logit_lens, *target_lens;
     float *denom_s, *lpb_s, *lpe_s;  // skewed [B,D,U1] softmax statistics (forward epilogue)

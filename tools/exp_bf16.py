@@ -18,7 +18,7 @@ def timeit(stage, n=3):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n
 names = {1: "fwd", 4: "dhidden", 6: "dw"}
-cases = [(0, "normal"), (256, "no stores"), (768, "no stores/stats"),
+cases = [(0, "normal"), (4096, "no A/logits loads only"), (2048, "no W loads only"), (512, "no stats only"), (1024, "no MFMA only"), (256, "no stores"), (768, "no stores/stats"),
          (1024 + 768, "no MFMA/stores/stats"), (1024 + 768 + 2048, "..and no W loads"),
          (1024 + 768 + 4096, "..and no A/logits loads"), (1024 + 768 + 2048 + 4096, "..and neither"),
          (8192 + 256, "no dh epilogue/stores"), (8192 + 256 + 2048, "..and no W loads"),
