@@ -18,6 +18,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------------
 // log-softmax denominators + the two log-probs each lattice cell needs.
 // One wave per (b,t,u) row; V % 4 == 0.
@@ -176,6 +178,150 @@ __device__ __forceinline__ void lattice_sweep(
 }
 
 // ---------------------------------------------------------------------------------------
+// Wave-chain sweep (used whenever its mailboxes fit in LDS): thread u owns column u as above, but
+// the waves of the workgroup are NOT joined by a barrier per step.  Inside a wave the neighbour
+// column of the previous diagonal moves by a DPP wave shift (no LDS in the dependent chain); the
+// one value per step that crosses a wave boundary goes through an LDS mailbox [boundary][step]
+// (value, then tag = step+1; written and read in program order, so a matching tag guarantees the
+// value) that the consuming wave reads one step ahead of its use.  The dependency is one-way
+// (alpha: wave w needs wave w-1; beta: w needs w+1), a producer never waits, so the waves settle
+// one step behind each other like a systolic array and a step costs its own ~45 instructions
+// instead of LDS write -> s_barrier -> LDS read across four waves (cfg2: 0.36 -> see DESIGN).
+// Every mailbox slot is written exactly once (no ring, no back-pressure); the consumer's spin is
+// bounded, so every wave reaches its exit whatever happens.
+template <int CTRL>
+__device__ __forceinline__ double wave_shift(double v, double fill)
+{
+    const u32x2_t x = __builtin_bit_cast(u32x2_t, v), f = __builtin_bit_cast(u32x2_t, fill);
+    u32x2_t r;
+    r[0] = (unsigned)__builtin_amdgcn_update_dpp((int)f[0], (int)x[0], CTRL, 0xf, 0xf, false);
+    r[1] = (unsigned)__builtin_amdgcn_update_dpp((int)f[1], (int)x[1], CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, r);
+}
+
+#define LAT_PF 6
+template <int DIR>
+__device__ __forceinline__ void lattice_chain(
+    const float *__restrict__ lpb_s, const float *__restrict__ lpe_s, double *__restrict__ out_s,
+    const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
+    float *__restrict__ costs, int U1, int D)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int NW = blockDim.x >> 6;
+    const int u = threadIdx.x, l = u & 63;
+    const int w = __builtin_amdgcn_readfirstlane(u >> 6);
+    // explicit LDS address space: volatile accesses through a generic pointer become flat_* ops
+    typedef __attribute__((address_space(3))) volatile double lds_f64;
+    typedef __attribute__((address_space(3))) volatile int lds_i32;
+    lds_f64 *mval = (lds_f64 *)sm;                        // [NW-1][D]
+    lds_i32 *mtag = (lds_i32 *)(sm + (size_t)(NW - 1) * D);  // [NW-1][D]
+    for (int i = u; i < (NW - 1) * D; i += blockDim.x) mtag[i] = 0;
+    __syncthreads();  // the only barrier of the sweep
+
+    const int b = blockIdx.x;
+    const int Tb = logit_lens[b], Ub = target_lens[b];
+    const int nd = Tb + Ub;  // valid anti-diagonals 0 .. nd-1
+    const long base = (long)b * D * U1;
+    const float *lpb = lpb_s + base, *lpe = lpe_s + base;
+    double *out = out_s + base;
+    const double NINF = (double)RNNT_NEG_INF;
+    const int ukey = u <= Ub ? u : (1 << 30);  // a key no diagonal matches outside the lattice
+    const bool st_ok = u < U1;
+    const int uc = st_ok ? u : U1 - 1;
+    // alpha: wave w publishes its lane 63 into boundary w and consumes boundary w-1;
+    // beta:  wave w publishes its lane 0 into boundary w-1 and consumes boundary w
+    const bool has_prod = DIR == 0 ? w < NW - 1 : w > 0;
+    const bool has_cons = DIR == 0 ? w > 0 : w < NW - 1;
+    const int pb = (DIR == 0 ? w : w - 1) * D, cb = (DIR == 0 ? w - 1 : w) * D;
+    const bool plane = l == (DIR == 0 ? 63 : 0);
+
+    // lp values of the transitions INTO the cells of step k (diagonal d = k / nd-1-k): alpha from
+    // the cells of diagonal d-1 (columns u and u-1), beta the cell's own.  Clamped to <= 0 (a
+    // log-prob; whatever an unwritten slot holds, NaN included, becomes harmless: it is only ever
+    // added to -inf or dropped by the validity select).
+    auto fetch = [&](int k, float &lb, float &le) {
+        const int kk = k < nd ? k : nd - 1;  // k >= 1
+        if (DIR == 0) {
+            const long r = (long)(kk - 1) * U1;
+            lb = lpb[r + uc];
+            le = lpe[r + (uc > 0 ? uc - 1 : 0)];
+        } else {
+            const long r = (long)(nd - 1 - kk) * U1;
+            lb = lpb[r + uc];
+            le = lpe[r + uc];
+        }
+    };
+    auto publish = [&](int k, double v) {
+        if (has_prod && plane) {
+            mval[pb + k] = v;
+            mtag[pb + k] = k + 1;
+        }
+    };
+
+    // ---- step 0: alpha[0,0] = 0; beta[Tb-1,Ub] = lp_blank there
+    double prev;
+    {
+        const int d = DIR == 0 ? 0 : nd - 1;
+        const double first = DIR == 0 ? 0.0 : (double)lpb[(long)d * U1 + Ub];
+        prev = (u == (DIR == 0 ? 0 : Ub)) ? first : NINF;
+        if (st_ok) out[(long)d * U1 + u] = prev;
+        publish(0, prev);
+    }
+    float lbr[LAT_PF], ler[LAT_PF];
+#pragma unroll
+    for (int q = 0; q < LAT_PF; ++q) fetch(1 + q, lbr[q], ler[q]);
+    // mailbox of step k-1, requested one step early
+    int tg = 0;
+    double bv = NINF;
+    if (has_cons) { tg = mtag[cb]; bv = mval[cb]; }
+    for (int k0 = 1; k0 < nd; k0 += LAT_PF) {
+#pragma unroll
+        for (int q = 0; q < LAT_PF; ++q) {
+            const int k = k0 + q;
+            if (k < nd) {  // workgroup-uniform
+                const int d = DIR == 0 ? k : nd - 1 - k;
+                if (has_cons) {  // wave-uniform
+                    for (int spin = 0; tg != k && spin < (1 << 22); ++spin) { tg = mtag[cb + k - 1]; bv = mval[cb + k - 1]; }
+                }
+                // neighbour column of the previous diagonal: u-1 (alpha) / u+1 (beta); the lane at
+                // the wave's edge keeps the mailbox value (-inf at the lattice's edge)
+                const double nb = DIR == 0 ? wave_shift<0x138>(prev, bv) : wave_shift<0x130>(prev, bv);
+                if (has_cons && k + 1 < nd) { tg = mtag[cb + k]; bv = mval[cb + k]; }  // next step's, early
+                float lb = lbr[q], le = ler[q];
+                asm("v_min_f32 %0, 0, %0" : "+v"(lb));  // plain min: fminf() adds a canonicalising v_max
+                asm("v_min_f32 %0, 0, %0" : "+v"(le));
+                const double a = prev + (double)lb;
+                const double e = nb + (double)le;
+                // log(exp(a) + exp(e)) = max + log(1 + exp(-|a - e|)); the correction is < ln 2 and
+                // evaluated in fp32 with the hardware exp2/log2.  A cell of the lattice has at
+                // least one finite predecessor; everything else is overwritten by the select.
+                const float dl = -fabsf((float)(a - e));
+                const double v = fmax(a, e) +
+                    (double)(__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(dl * RNNT_LOG2E)) * 0.6931471805599453f);
+                const bool valid = (unsigned)(d - ukey) < (unsigned)Tb;
+                prev = valid ? v : NINF;
+                publish(k, prev);
+                if (st_ok) out[(long)d * U1 + u] = prev;
+            }
+            fetch(k + LAT_PF, lbr[q], ler[q]);
+        }
+    }
+    if (DIR == 1 && u == 0) costs[b] = (float)(-prev);  // -beta[0,0]
+}
+
+__global__ __launch_bounds__(1024) void k_lattice_chain(
+    const float *__restrict__ lpb_s, const float *__restrict__ lpe_s,
+    double *__restrict__ alpha_s, double *__restrict__ beta_s,
+    const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
+    float *__restrict__ costs, int U1, int D)
+{
+    if (blockIdx.y == 0)
+        lattice_chain<0>(lpb_s, lpe_s, alpha_s, logit_lens, target_lens, costs, U1, D);
+    else
+        lattice_chain<1>(lpb_s, lpe_s, beta_s, logit_lens, target_lens, costs, U1, D);
+}
+
+// ---------------------------------------------------------------------------------------
 // Per-cell gradient coefficients.  One thread per skewed slot (b,d,u); reads are coalesced
 // rows of the skewed arrays, the 16-byte CellCoef is written at the cell's natural
 // (b,t,u) index where the GEMM kernels gather it.
@@ -275,6 +421,13 @@ void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, dou
                     const int32_t *logit_lens, const int32_t *target_lens, float *costs, int B,
                     int U1, int D, hipStream_t st)
 {
+    const int NW = (U1 + 63) / 64;
+    const size_t mbox = (size_t)(NW - 1) * D * 12;  // chain mailboxes: 8 B value + 4 B tag per boundary and step
+    if (mbox <= 64 * 1024) {
+        hipLaunchKernelGGL(k_lattice_chain, dim3(B, 2), dim3(64 * NW), (mbox + 15) / 16 * 16, st, lpb_s, lpe_s, alpha_s,
+                           beta_s, logit_lens, target_lens, costs, U1, D);
+        return;
+    }
     const int NT = ((U1 + 63) / 64) * 64;
     const size_t lds = 2 * (size_t)(NT + 2) * sizeof(double);
     hipLaunchKernelGGL(k_lattice, dim3(B, 2), dim3(NT), lds, st, lpb_s, lpe_s, alpha_s, beta_s,
