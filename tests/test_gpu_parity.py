@@ -83,9 +83,10 @@ def test_fused_noncontiguous_encoder_view(amd):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 0, 4), (2, 6, 3, 8), (3, 31, 17, 40), (2, 20, 9, 1024),
-                                   (2, 8, 4, 7), (1, 130, 70, 16)])
+                                   (2, 8, 4, 7), (1, 130, 70, 16), (2, 70, 200, 8), (2, 1400, 300, 8)])
 def test_loss_only_vs_oracle(amd, shape):
-    """rnnt_loss on given logits == the call at reference rnnt/model.py:35-41."""
+    """rnnt_loss on given logits == the call at reference rnnt/model.py:35-41.  The last two shapes
+    put the lattice sweep on four chained waves and (mailboxes > 64 KB) on the barrier kernel."""
     from oracle import cpu_oracle
     B, T, U, V = shape
     rng = np.random.default_rng(sum(shape))
