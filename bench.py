@@ -130,8 +130,14 @@ def main():
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     device = torch.device("cuda", 0 if single else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: run the N>1 code path (process group, broadcast, all-reduce, barriers)
+    # with a single rank, so the RCCL calls can be exercised on a one-GPU box
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
         else:
@@ -146,7 +152,7 @@ def main():
         raise SystemExit(f"global batch {B} not divisible by {world} ranks")
     Bl = B // world  # contiguous batch shard per rank (strong scaling: global batch fixed)
     enc, pred, W, bias, targets, ll, tl = synth(Bl, T, U, H, V, 1234 + rank, device)
-    if world > 1:  # parameters are replicated: rank 0's W/bias everywhere
+    if dist_on:  # parameters are replicated: rank 0's W/bias everywhere
         dist.broadcast(W, 0); dist.broadcast(bias, 0)
     scale = 1.0 / B
     # flat [dW | db | loss] buffer: grad_W / grad_bias are views, so the all-reduce needs no copy
@@ -166,18 +172,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss = float(flat[V * H + V].item())
@@ -202,7 +208,7 @@ def main():
             stage_ms[name] = e0.elapsed_time(e1) / reps
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -271,7 +277,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(T, U, H, V)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -20,5 +20,5 @@ for DT in fp32 bf16; do
     python3 tools/pmc_summary.py $(ls gpurun_out/$TAG.$DT/$C/*/*counter_collection.csv | head -1) > gpurun_out/$TAG.$DT.$C.txt
   done
 done
-timeout -k 10 100 python3 bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/$TAG.bf16.default.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --dtype bf16 > gpurun_out/$TAG.bf16.default.json 2>/dev/null
 echo "bf16 default rc=$?"
