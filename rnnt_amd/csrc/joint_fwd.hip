@@ -329,30 +329,61 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         // 13 GB pass (k_make_hidden): ~1 % of the tile's time, and the main loop's loads of it hit
         // L2.  EVERY cell of the utterance gets a finite row, also past its length: the backward
         // GEMMs multiply those rows by exact zeros.
-        // Wave w takes rows w, w+8, ...; a lane takes 4 consecutive h.  All loads of a batch of 8
-        // rows are issued before the first tanh so a tile pays ~4 memory round trips, not 32.
+        // Wave w takes rows w, w+8, ...; a lane takes 4 consecutive h.  Loads are batched ahead of
+        // the first tanh so a tile pays a few memory round trips, not one per row: when the tile
+        // spans at most two time steps (U1 >= 127) its two enc rows are loaded once and all 16 pred
+        // rows of the wave are in flight together (one round trip per 256 columns); otherwise
+        // batches of 8 (enc, pred) row pairs.
         const int nrow = T * U1 - m0 < FWD_ROWS ? T * U1 - m0 : FWD_ROWS;
         float *hid = (float *)a.hidden + ((long)b * T * U1 + m0) * H;
         const float *encb = a.enc + (long)b * a.enc_sb, *predb = a.pred + (long)b * U1 * H;
-        constexpr int NW = FWD_THREADS / 64, BATCH = 8;
-        for (int h = (tid & 63) * 4; h < H; h += 256) {
-            for (int rb = 0; rb < FWD_ROWS / NW; rb += BATCH) {
-                f32x4 e[BATCH], p[BATCH];
+        constexpr int NW = FWD_THREADS / 64, RPW = FWD_ROWS / NW;
+        const int t_first = m0 / U1;
+        const int cut = (t_first + 1) * U1 - m0;  // tile rows >= cut belong to time step t_first + 1
+        if ((m0 + nrow - 1) / U1 <= t_first + 1) {
+            const int t_second = t_first + 1 < T ? t_first + 1 : t_first;
+            for (int h = (tid & 63) * 4; h < H; h += 256) {
+                const f32x4 e0 = *(const f32x4 *)(encb + (long)t_first * a.enc_st + h);
+                const f32x4 e1 = *(const f32x4 *)(encb + (long)t_second * a.enc_st + h);
+                f32x4 p[RPW];
 #pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int r = wave + (rb + i) * NW;
-                    const int c = m0 + (r < nrow ? r : nrow - 1);  // clamped: loads stay unconditional
-                    const int t = c / U1, u = c - t * U1;
-                    e[i] = *(const f32x4 *)(encb + (long)t * a.enc_st + h);
+                for (int i = 0; i < RPW; ++i) {
+                    const int r0 = wave + i * NW;
+                    const int r = r0 < nrow ? r0 : nrow - 1;  // clamped: loads stay unconditional
+                    const int u = m0 + r - (r >= cut ? t_first + 1 : t_first) * U1;
                     p[i] = *(const f32x4 *)(predb + (long)u * H + h);
                 }
 #pragma unroll
-                for (int i = 0; i < BATCH; ++i) {
-                    const int r = wave + (rb + i) * NW;
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = wave + i * NW;
+                    const f32x4 e = r >= cut ? e1 : e0;  // wave-uniform
                     f32x4 o;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[i][q] + p[i][q]);
+                    for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[q] + p[i][q]);
                     if (r < nrow) *(f32x4 *)(hid + (long)r * H + h) = o;
+                }
+            }
+        } else {
+            constexpr int BATCH = 8;
+            for (int h = (tid & 63) * 4; h < H; h += 256) {
+                for (int rb = 0; rb < RPW; rb += BATCH) {
+                    f32x4 e[BATCH], p[BATCH];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int r = wave + (rb + i) * NW;
+                        const int c = m0 + (r < nrow ? r : nrow - 1);
+                        const int t = c / U1, u = c - t * U1;
+                        e[i] = *(const f32x4 *)(encb + (long)t * a.enc_st + h);
+                        p[i] = *(const f32x4 *)(predb + (long)u * H + h);
+                    }
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int r = wave + (rb + i) * NW;
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[i][q] + p[i][q]);
+                        if (r < nrow) *(f32x4 *)(hid + (long)r * H + h) = o;
+                    }
                 }
             }
         }
