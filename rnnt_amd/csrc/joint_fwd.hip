@@ -24,7 +24,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#define FWD_MWAVES 4  // 8 waves = 4 (M) x 2 (N): two waves per SIMD
+#define FWD_MWAVES 2  // 4 waves = 2 (M) x 2 (N), one per SIMD; TWO workgroups per CU (BREG path)
 #define FWD_ROWS (32 * FWD_MWAVES)
 #define FWD_THREADS (128 * FWD_MWAVES)
 
@@ -133,8 +133,9 @@ __device__ __forceinline__ void vm_wait(f32x4 &e, f32x4 &p)
 // no difference and was dropped with its wrap-around arithmetic.)  W is zero-padded in wpack,
 // tanh of any finite input is finite, and address clamps keep every load in bounds, so no load
 // in the loop is conditional.
-template <bool USE_HID, bool PAIRS>  // USE_HID: erow points at the precomputed hidden row (no tanh, no pred)
+template <bool USE_HID, bool PAIRS, bool BREG = false>  // USE_HID: erow points at the precomputed hidden row (no tanh, no pred)
                                      // PAIRS (with USE_HID, even chunk count): two-set form below
+                                     // BREG (with PAIRS): B fragments straight L2 -> VGPR, no LDS, no barrier
 __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *prow,
                                              const f32x4 *wpass, int gvalid, int HK,
                                              long wstride, int H, int half, int wave,
@@ -151,8 +152,9 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
     const int a_last = 8 * last - back;  // per-lane offset of the last chunk's A slice
     // this wave's share of a chunk's DMA: float4 [wave*128, +128) of the 1024; column groups
     // beyond the last valid one of a partial pass re-read group 0 (their tiles are discarded)
-    const int dgrp = wave >> 1;
-    const unsigned dlane = (unsigned)(((dgrp < gvalid ? wave * 128 : (wave & 1) * 128) + lane) * 16);  // bytes
+    constexpr int DPW = 1024 / FWD_THREADS;  // 1 KiB DMA pieces per wave and chunk
+    const int dgrp = wave * DPW / 4;
+    const unsigned dlane = (unsigned)(((dgrp < gvalid ? wave * 64 * DPW : (wave * 64 * DPW) % 256) + lane) * 16);  // bytes
     // LDS-DMA: the chunk's two 1 KiB pieces share one address and one M0 — the second is the
     // first at instruction offset 1024, which moves the global AND the LDS address.  (As MUBUF
     // `buffer_load ... lds` with a scalar chunk offset the address arithmetic disappears too, but
@@ -160,13 +162,85 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
     const unsigned wstride_b = (unsigned)(wstride * 16);
     const char *wlane = (const char *)wpass + dlane;  // per-lane source of chunk 0
     auto dma = [&](unsigned chunk_off, int slot) {  // chunk_off: uniform byte offset of the chunk
-        f32x4 *dst = ldsb + slot * FWD_BCHUNK + wave * 128;  // wave-uniform (goes to M0)
+        f32x4 *dst = ldsb + slot * FWD_BCHUNK + wave * 64 * DPW;  // wave-uniform (goes to M0)
         __builtin_amdgcn_global_load_lds((const void *)(wlane + chunk_off), (lds_void_ptr)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void *)(wlane + chunk_off), (lds_void_ptr)dst, 16, 1024, 0);
+        if (DPW == 4) {
+            __builtin_amdgcn_global_load_lds((const void *)(wlane + chunk_off), (lds_void_ptr)dst, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds((const void *)(wlane + chunk_off), (lds_void_ptr)dst, 16, 3072, 0);
+        }
     };
     const int roff = wn * 512 + lane;  // this wave's first fragment inside a staged chunk
     unsigned wnext = 0;  // byte offset of the chunk the next DMA fetches
 
+    if constexpr (USE_HID && PAIRS && BREG) {
+        // Default path.  No LDS in the loop: every wave streams its own 8 B fragments per chunk from wpack
+        // (fragment order: one coalesced 1 KiB load each; the four M-waves of a column half and
+        // the CU's other workgroup hit the same lines in L1/L2) into two register sets that
+        // alternate by chunk parity, exactly like the A slices.  A fragment register is
+        // re-requested for chunk c+2 one tile (4 MFMAs) after its last use — a refill issued
+        // while MFMAs still read the register blocks the wave's issue.  No DMA, no ds_read, no
+        // s_barrier: the loop carries ~10 non-MFMA instructions per 32 MFMAs instead of ~30.
+        // Measured against the LDS-DMA ring below (8-wave workgroups, one per CU): the same
+        // 52.1 ms at cfg2 — and the same again with one or two of these 4-wave workgroups per CU
+        // (52.9 / 52.2 ms): neither the instruction count, the barrier, LDS nor a second wave per
+        // SIMD is what holds the loop at ~89 % of the matrix pipe.  Kept because it is the simpler
+        // loop and leaves the LDS to the softmax state.
+        const int g0i = 2 * wn, g1i = 2 * wn + 1;  // this wave's column groups of the pass
+        const unsigned v0 = (unsigned)(((g0i < gvalid ? g0i * 256 : 0) + lane) * 16);  // groups past the
+        const unsigned v1 = (unsigned)(((g1i < gvalid ? g1i * 256 : 0) + lane) * 16);  // matrix re-read group 0
+        const char *wbase = (const char *)wpass;
+        const unsigned wsb = (unsigned)(wstride * 16);
+        auto aoff = [&](int c) { return c >= last ? a_last : 8 * c; };
+        // hipcc-invisible loads (see asm_load16): uniform chunk base in SGPRs + 32-bit lane offset
+        // + immediate tile offset, so a chunk's address update is two scalar adds
+#define LDW(dst, base, q)                                                                        \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                  \
+                     : "+v"(dst) : "v"((q) < 4 ? v0 : v1), "s"(base), "n"(((q) & 3) * 1024) : "memory")
+        f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea, wa[8], wb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { wa[q] = ea; wb[q] = ea; }
+        const char *b1 = wbase + (HK > 1 ? wsb : 0);              // chunk c8+1 (clamped to the last)
+        const char *b2 = HK > 2 ? wbase + 2 * (size_t)wsb : b1;    // chunk c8+2
+        asm_load16(ea, erow + aoff(0));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) LDW(wa[q], wbase, q);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) LDW(wb[q], b1, q);
+        __builtin_amdgcn_sched_barrier(0);
+        // In flight at the top of chunk c8: the 7 re-requests chunk c8-1 made for its own set.
+        // Everything older — this chunk's A slice and fragment 7 (requested at the start of
+        // c8-1), fragments 0-6 (during c8-2) — has landed once vmcnt <= 7.
+        auto chunk = [&](int c8, f32x4 &eu, f32x4 (&wu)[8], f32x4 &ep, f32x4 (&wp)[8]) {
+            asm volatile("s_waitcnt vmcnt(7)"
+                         : "+v"(eu), "+v"(wu[0]), "+v"(wu[1]), "+v"(wu[2]), "+v"(wu[3]), "+v"(wu[4]),
+                           "+v"(wu[5]), "+v"(wu[6]), "+v"(wu[7])
+                         :: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(eu[s], wu[q][s], acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == 0) {  // what chunk c8-1 could not re-request while its last MFMAs ran
+                    LDW(wp[7], b1, 7);
+                    asm_load16(ep, erow + aoff(c8 + 1));
+                } else {
+                    LDW(wu[q - 1], b2, q - 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            b1 = b2;
+            if (c8 + 3 <= last) b2 += wsb;
+        };
+        for (int c8 = 0; c8 < HK; c8 += 2) {
+            chunk(c8, ea, wa, eb, wb);
+            chunk(c8 + 1, eb, wb, ea, wa);
+        }
+#undef LDW
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land after the registers are reused
+        return;
+    }
     f32x4 w[8];
     if constexpr (USE_HID && PAIRS) {
         // Hot path (A = precomputed hidden rows): the MFMAs read the loaded registers themselves.
@@ -194,7 +268,7 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
         // MFMA).  At the top of chunk c8 the 3 ops of chunk c8-1 may stay in flight; everything
         // older — this chunk's A (requested at the end of c8-2) and the B of chunk c8+1 — is in.
         auto chunk = [&](int c8, f32x4 &eu) {
-            vm_wait<3>(ea, eb);
+            vm_wait<DPW + 1>(ea, eb);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 *rd = ldsb + ((c8 + 1) & (FWD_NBUF - 1)) * FWD_BCHUNK + roff;
@@ -250,7 +324,7 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
     for (int c8 = 0; c8 < HK; ++c8) {
         // retire this wave's A slices and its share of the DMA issued two chunks ago (step
         // c8+1's B); the newest DMA (2 ops) stays in flight across the barrier
-        vm_wait<2>(e, p);
+        vm_wait<DPW>(e, p);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 *rd = ldsb + ((c8 + 1) & (FWD_NBUF - 1)) * FWD_BCHUNK + roff;
@@ -302,17 +376,19 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
 #define STAMP(slot)
 #endif
 
-template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false, bool MAKE_HID = false>
+template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false, bool MAKE_HID = false, bool BREG = false>
 __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
 {
     // ALL LDS in one array (hipcc otherwise guards every ds_read with vmcnt(0) while an LDS-DMA
     // is in flight): [B ring | per-lane running softmax state | per-row (max,sum) of 2 N-waves]
-    __shared__ __attribute__((aligned(16))) char smem[FWD_NBUF * FWD_BCHUNK * 16 +
-                                                      16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4];
+    // The BREG main loop keeps no B ring: 33 KB, so two workgroups share a CU and one's prologue /
+    // epilogues / finalisation run under the other's MFMAs; the ring variants (odd chunk counts,
+    // the plain joint) need 97 KB and run one workgroup per CU.
+    constexpr int RING = BREG ? 0 : FWD_NBUF * FWD_BCHUNK * 16;
+    __shared__ __attribute__((aligned(16))) char smem[RING + 16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4];
     f32x4 *s_b = (f32x4 *)smem;
-    float2(*s_run2)[FWD_THREADS] = (float2(*)[FWD_THREADS])(smem + FWD_NBUF * FWD_BCHUNK * 16);
-    float(*s_m)[FWD_ROWS] =
-        (float(*)[FWD_ROWS])(smem + FWD_NBUF * FWD_BCHUNK * 16 + 16 * FWD_THREADS * 8);
+    float2(*s_run2)[FWD_THREADS] = (float2(*)[FWD_THREADS])(smem + RING);
+    float(*s_m)[FWD_ROWS] = (float(*)[FWD_ROWS])(smem + RING + 16 * FWD_THREADS * 8);
     float(*s_s)[FWD_ROWS] = s_m + 2;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -446,7 +522,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
         const int gvalid = min(4, NG - pass * 4);
         STAMP(1 + 2 * (pass & 1));
-        fwd_mainloop<USE_HID, PAIRS>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
+        fwd_mainloop<USE_HID, PAIRS, BREG>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
                                 s_b, acc);
         STAMP(2 + 2 * (pass & 1));
 
@@ -553,7 +629,8 @@ void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
     dim3 grid(tiles, a.B), block(FWD_THREADS);
     if (a.denom_s && a.hidden) {
         const bool pairs = ((a.H + 7) / 8) % 2 == 0;  // even number of 8-wide chunks: the two-register-set main loop
-        if (a.make_hidden && pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true, true>), grid, block, 0, st, a);
+        if (a.make_hidden && pairs && !(a.flags & 128)) hipLaunchKernelGGL((k_joint_fwd<true, true, true, true, true>), grid, block, 0, st, a);
+        else if (a.make_hidden && pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true, true>), grid, block, 0, st, a);
         else if (a.make_hidden) hipLaunchKernelGGL((k_joint_fwd<true, true, false, true>), grid, block, 0, st, a);
         else if (pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_joint_fwd<true, true>), grid, block, 0, st, a);

@@ -1,0 +1,32 @@
+"""Experiment: forward main loop with B fragments streamed L2 -> VGPR (default) against the
+LDS-DMA ring variant (rnnt_engine_set_flags(128)); cfg2 fp32 stage times."""
+import sys
+sys.path.insert(0, ".")
+import torch
+from rnnt_amd import engine
+import bench
+
+if __name__ == "__main__":
+    dev = torch.device("cuda", 0)
+    B, T, U, H, V = bench.CONFIGS["cfg2"]
+    enc, pred, W, bias, targets, ll, tl = bench.synth(B, T, U, H, V, 1234, dev)
+    def run(stage=None):
+        kw = {} if stage is None else {"stage": stage}
+        return engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1.0 / 32, **kw)
+    def timed(stage=None, reps=5):
+        run(stage); run(stage)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run(stage)
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ref = None
+    for flags in (0, 128, 0, 128):
+        engine.lib().rnnt_engine_set_flags(flags)
+        outs = [o.clone() for o in run()]
+        if ref is None:
+            ref = outs
+        err = max(float((a - b).abs().max()) for a, b in zip(outs, ref))
+        print(f"flags {flags:4d}: step {timed():7.2f} ms  fwd {timed(1):6.2f} ms  max|diff vs default| {err:.3g}", flush=True)
+    engine.lib().rnnt_engine_set_flags(0)
