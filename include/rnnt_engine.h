@@ -54,7 +54,8 @@ int rnnt_engine_version(void);
 /* Experiment switches read by the ablation code of diagnostic builds (-DRNNT_ABLATE; the shipped
  * kernels ignore them), bit 5 (32): force the separate k_make_g pass, and bit 6 (64): force the
  * separate k_make_hidden pass (the forward kernel otherwise fills hidden itself), bit 7 (128): forward
- * main loop with the LDS-DMA ring for W instead of register-streamed fragments.  Returns the old value. */
+ * main loop with the LDS-DMA ring for W instead of register-streamed fragments, bit 8 (256): forward
+ * launched as one workgroup per tile instead of persistent workgroups.  Returns the old value. */
 int rnnt_engine_set_flags(int flags);
 
 /* Device buffer for diagnostic in-kernel time stamps; only read by builds made with

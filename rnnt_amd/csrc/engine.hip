@@ -234,6 +234,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
         f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = g_flags; f.debug = g_debug;
         f.make_hidden = fuse_hid ? 1 : 0;
+        f.counter = (unsigned *)(ws + L.counters + 512); f.n_cu = device_cus();
         launch_joint_fwd(f, st);
     }
     if (stages & ST_LATTICE)

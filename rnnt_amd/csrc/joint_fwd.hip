@@ -369,15 +369,16 @@ __device__ __forceinline__ void fwd_mainloop(const float *erow, const float *pro
         if (a.debug && tid == 0) {                                                           \
             unsigned long long t_;                                                           \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-            a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (slot)] = t_;          \
+            a.debug[((long)by_ * ntx_ + bx_) * 32 + (slot)] = t_;          \
         }                                                                                    \
     } while (0)
 #else
 #define STAMP(slot)
 #endif
 
-template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false, bool MAKE_HID = false, bool BREG = false>
-__global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
+// One tile (FWD_ROWS cells of utterance by_, tile bx_ of ntx_) of the forward GEMM + epilogues.
+template <bool WITH_LOSS, bool USE_HID, bool PAIRS, bool MAKE_HID, bool BREG>
+__device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, const int by_, const int ntx_, char *smem)
 {
     // ALL LDS in one array (hipcc otherwise guards every ds_read with vmcnt(0) while an LDS-DMA
     // is in flight): [B ring | per-lane running softmax state | per-row (max,sum) of 2 N-waves]
@@ -385,7 +386,6 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     // epilogues / finalisation run under the other's MFMAs; the ring variants (odd chunk counts,
     // the plain joint) need 97 KB and run one workgroup per CU.
     constexpr int RING = BREG ? 0 : FWD_NBUF * FWD_BCHUNK * 16;
-    __shared__ __attribute__((aligned(16))) char smem[RING + 16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4];
     f32x4 *s_b = (f32x4 *)smem;
     float2(*s_run2)[FWD_THREADS] = (float2(*)[FWD_THREADS])(smem + RING);
     float(*s_m)[FWD_ROWS] = (float(*)[FWD_ROWS])(smem + RING + 16 * FWD_THREADS * 8);
@@ -395,8 +395,8 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: M0 of the DMAs, no per-use readfirstlane
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
-    const int b = blockIdx.y;
-    const int m0 = blockIdx.x * FWD_ROWS;
+    const int b = by_;
+    const int m0 = bx_ * FWD_ROWS;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int Tb = WITH_LOSS ? a.logit_lens[b] : T;
     const int ncell = Tb * U1;
@@ -472,10 +472,10 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 8 + wave] =
+        a.debug[((long)by_ * ntx_ + bx_) * 32 + 8 + wave] =
             ((unsigned long long)xcc << 32) | hw;
         if (wave == 0)
-            a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 7] =
+            a.debug[((long)by_ * ntx_ + bx_) * 32 + 7] =
                 ((unsigned long long)xcc << 32) | hw;
     }
 #endif
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     if (a.debug && lane == 0) {
         unsigned long long t_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        a.debug[((long)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 16 + wave] = t_;
+        a.debug[((long)by_ * ntx_ + bx_) * 32 + 16 + wave] = t_;
     }
 #endif
     if (WITH_LOSS) {
@@ -623,13 +623,54 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
     STAMP(6);
 }
 
+#define FWD_SMEM(BREG) ((BREG ? 0 : FWD_NBUF * FWD_BCHUNK * 16) + 16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4)
+
+// one workgroup per tile, grid (tiles per utterance, B)
+template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false, bool MAKE_HID = false, bool BREG = false>
+__global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd(JointFwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char smem[FWD_SMEM(BREG)];
+    fwd_tile<WITH_LOSS, USE_HID, PAIRS, MAKE_HID, BREG>(a, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+
+// Persistent form of the default path: 2 workgroups per CU for the whole launch, tiles handed out
+// by one atomic counter.  With one workgroup per tile the dispatcher does not keep the second
+// slot of a CU filled (stamps: 1.1-1.2 resident workgroups per CU on average, every tile's
+// prologue / epilogues / finalisation — 10 % of its time — run with the matrix pipe idle);
+// resident workgroups drift apart and one's non-MFMA phases run under the other's MFMAs.
+template <bool WITH_LOSS, bool USE_HID, bool PAIRS, bool MAKE_HID, bool BREG>
+__global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd_persist(JointFwdArgs a, int ntx, int ntot)
+{
+    __shared__ __attribute__((aligned(16))) char smem[FWD_SMEM(BREG)];
+    __shared__ int s_next;
+    if (threadIdx.x == 0) s_next = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    int t = s_next;
+    while (t < ntot) {
+        fwd_tile<WITH_LOSS, USE_HID, PAIRS, MAKE_HID, BREG>(a, t % ntx, t / ntx, ntx, smem);
+        __syncthreads();  // every wave done with the tile's LDS state (and with s_next)
+        if (threadIdx.x == 0) s_next = (int)atomicAdd(a.counter, 1u);
+        __syncthreads();
+        t = s_next;
+    }
+}
+
 void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
 {
     const int tiles = (int)(((long)a.T * a.U1 + FWD_ROWS - 1) / FWD_ROWS);
     dim3 grid(tiles, a.B), block(FWD_THREADS);
     if (a.denom_s && a.hidden) {
         const bool pairs = ((a.H + 7) / 8) % 2 == 0;  // even number of 8-wide chunks: the two-register-set main loop
-        if (a.make_hidden && pairs && !(a.flags & 128)) hipLaunchKernelGGL((k_joint_fwd<true, true, true, true, true>), grid, block, 0, st, a);
+        if (a.make_hidden && pairs && !(a.flags & 128)) {
+            const long ntot = (long)tiles * a.B;
+            if (a.counter && !(a.flags & 256) && ntot < 0x7fffffffL) {
+                (void)hipMemsetAsync(a.counter, 0, 4, st);
+                const int nwg = (int)(ntot < 2L * a.n_cu ? ntot : 2L * a.n_cu);
+                hipLaunchKernelGGL((k_joint_fwd_persist<true, true, true, true, true>), dim3(nwg), block, 0, st, a, tiles, (int)ntot);
+            } else {
+                hipLaunchKernelGGL((k_joint_fwd<true, true, true, true, true>), grid, block, 0, st, a);
+            }
+        }
         else if (a.make_hidden && pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true, true>), grid, block, 0, st, a);
         else if (a.make_hidden) hipLaunchKernelGGL((k_joint_fwd<true, true, false, true>), grid, block, 0, st, a);
         else if (pairs) hipLaunchKernelGGL((k_joint_fwd<true, true, true>), grid, block, 0, st, a);

@@ -31,6 +31,8 @@ struct JointFwdArgs {
     float *denom_s, *lpb_s, *lpe_s;  // skewed [B,D,U1]; NULL for the plain joint
     int B, T, U1, H, V, D, blank;
     int flags;  // bit0: non-temporal logits stores
+    unsigned *counter;  // one zeroable word: tile counter of the persistent forward (NULL: one workgroup per tile)
+    int n_cu;           // compute units
     unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
 };
 size_t wpack_floats(int H, int V);

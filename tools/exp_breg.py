@@ -1,5 +1,6 @@
-"""Experiment: forward main loop with B fragments streamed L2 -> VGPR (default) against the
-LDS-DMA ring variant (rnnt_engine_set_flags(128)); cfg2 fp32 stage times."""
+"""Experiment: forward kernel variants at cfg2 fp32 — default (persistent, 2 workgroups per CU, B
+fragments streamed L2 -> VGPR), rnnt_engine_set_flags(256): one workgroup per tile,
+rnnt_engine_set_flags(128): the LDS-DMA ring main loop."""
 import sys
 sys.path.insert(0, ".")
 import torch
@@ -22,7 +23,7 @@ if __name__ == "__main__":
         e1.record(); e1.synchronize()
         return e0.elapsed_time(e1) / reps
     ref = None
-    for flags in (0, 128, 0, 128):
+    for flags in (0, 256, 128, 0, 256, 128):
         engine.lib().rnnt_engine_set_flags(flags)
         outs = [o.clone() for o in run()]
         if ref is None:

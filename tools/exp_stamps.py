@@ -44,3 +44,29 @@ for k in np.unique(key)[:64]:
     cnt = [(en[:i] > st[i]).sum() + 1 for i in range(1, len(st))]
     ov.append(np.mean(cnt))
 print("mean number of co-resident workgroups on a CU at workgroup start (first 64 CUs):", np.mean(ov), " min", np.min(ov), " max", np.max(ov))
+# ---- time-integrated residency and relaunch latency per CU
+res, gaps = [], []
+for k in np.unique(key)[:64]:
+    m = key == k
+    st, en, slot = d[m, 0], d[m, 6], wv[m]
+    res.append((en - st).sum() / float(en.max() - st.min()))
+    for s_ in (0, 1):
+        ms = slot == s_
+        if ms.sum() > 2:
+            o = np.argsort(st[ms]); a, b = st[ms][o], en[ms][o]
+            gaps.extend((a[1:] - b[:-1]).tolist())
+print("time-integrated resident workgroups per CU: mean", np.mean(res), "min", np.min(res), "max", np.max(res))
+gaps = np.array(gaps)
+print("relaunch gap on the same (CU, wave slot), cycles: median", np.median(gaps), "p10", np.percentile(gaps, 10), "p90", np.percentile(gaps, 90))
+# ---- timeline of one CU
+k = np.unique(key)[5]
+m = key == k
+st, en, slot = d[m, 0], d[m, 6], wv[m]
+o = np.argsort(st); t00 = st.min()
+print("timeline of one CU (start, end, wave slot) in k-cycles:")
+for i in o[:24]:
+    print(f"   {int(st[i]-t00)//1000:7d} {int(en[i]-t00)//1000:7d}  slot {int(slot[i])}")
+o2 = o[len(o)//2:len(o)//2+16]
+print("   ... mid-kernel:")
+for i in o2:
+    print(f"   {int(st[i]-t00)//1000:7d} {int(en[i]-t00)//1000:7d}  slot {int(slot[i])}")
