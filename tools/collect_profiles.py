@@ -45,7 +45,7 @@ def pick(d, key):
     assert len(ks) == 1, (key, list(d))
     return d[ks[0]]
 
-names = {"cfg2": ("fp32", {"joint_fwd_gemm": "k_joint_fwd<", "dhidden_gemm": "k_dhidden_gen", "dw_gemm": "k_dw"}),
+names = {"cfg2": ("fp32", {"joint_fwd_gemm": "k_joint_fwd_persist<", "dhidden_gemm": "k_dhidden_gen", "dw_gemm": "k_dw"}),
          "cfg2_bf16": ("bf16", {"joint_fwd_gemm": "k_joint_fwd_bf16", "dhidden_gemm": "k_dhidden_bf16", "dw_gemm": "k_dw_bf16"})}
 alg = {"cfg2": {"joint_fwd_gemm": cells * (4 * H + 4 * H + 4 * V),  # writes hidden, reads it back, writes logits
                 "dhidden_gemm": cells * (4 * V + 4 * H + 4 * V) + 2.5e9,  # logits in, hidden in, G out, dEnc/dPred slabs
