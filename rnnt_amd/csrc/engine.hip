@@ -48,9 +48,9 @@ int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
     return RNNT_OK;
 }
 
-int dw_splits(int B, int T, int H, int V)
+int dw_splits(int B, int T, int H, int V, int dtype)
 {
-    const long tiles = (long)((V + 255) / 256) * ((H + 255) / 256);
+    const long tiles = dtype == RNNT_DTYPE_BF16 ? (long)((V + 255) / 256) * ((H + 255) / 256) : dw_tiles(H, V);
     long s = 256 / tiles;
     if (s < 1) s = 1;
     if (s > (long)B * T) s = (long)B * T;
@@ -71,7 +71,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->D = (int)D;
     L->n_ublk = (U1 + 15) / 16;
     L->n_ttile = (T + 3) / 4;
-    L->n_split = dw_splits(B, T, H, V);
+    L->n_split = dw_splits(B, T, H, V, dtype);
     size_t o = 0;
     if (dtype == RNNT_DTYPE_BF16) {
         const size_t ra = (size_t)bf16_rows_alloc(rows_pad);

@@ -744,6 +744,15 @@ void launch_make_g(const JointBwdArgs &a, hipStream_t st)
 #define DW_KC 16   // cells per split-range granule (row padding unit)
 #define DW_RING 8  // k-steps of operands in flight per wave
 
+// Workgroups per split: 2x2 blocks of 128x128 wave tiles (a 256x256 workgroup tile); when H has
+// an odd number of 128-column tiles (cfg4: H = 640) the last column is covered by 4x1 blocks
+// instead of a half-empty 256-wide tile (12 -> 10 workgroup tiles per split at cfg4).
+int dw_tiles(int H, int V)
+{
+    const int nv = (V + 127) / 128, nh = (H + 127) / 128;
+    return (nh / 2) * ((nv + 1) / 2) + (nh & 1) * ((nv + 3) / 4);
+}
+
 __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -751,8 +760,9 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
     const int H = a.H, V = a.V;
-    const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
-    const int tiles = n_vblk * n_hblk;
+    const int nv = (V + 127) / 128, nh = (H + 127) / 128;  // 128-wide wave tiles
+    const int n22 = (nh / 2) * ((nv + 1) / 2);                // 2x2 blocks
+    const int tiles = n22 + (nh & 1) * ((nv + 3) / 4);        // + 4x1 blocks of an odd last column
     const int total = tiles * a.n_split;
     // XCD-aware remap (bijective for any total): ids that are congruent mod 8 share an XCD
     int id = blockIdx.x;
@@ -761,8 +771,11 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
         id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + id / 8;
     }
     const int tile = id % tiles, split = id / tiles;
-    const int vb = tile / n_hblk, hb = tile % n_hblk;
-    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
+    // the waves never join, so a workgroup is just four wave tiles that share operands in L1
+    int vt, ht;
+    if (tile < n22) { vt = 2 * (tile / (nh / 2)) + wm; ht = 2 * (tile % (nh / 2)) + wn; }
+    else            { vt = 4 * (tile - n22) + wave;    ht = nh - 1; }
+    const int v0 = vt * 128, h0 = ht * 128;
     const int vbase = v0 + 4 * i, hbase = h0 + 4 * i;
     const bool vok = vbase < V, hok = hbase < H;
     const long nchunk = a.rows_pad / DW_KC;
@@ -847,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
                 }
             }
     }
-    if (hb == 0 && wn == 0) {
+    if (ht == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dbacc[q] += __shfl_xor(dbacc[q], 32, 64);
         if (half == 0 && vok) {
@@ -870,8 +883,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ 
 
 void launch_dw(const JointBwdArgs &a, hipStream_t st)
 {
-    const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
-    hipLaunchKernelGGL(k_dw, dim3(tiles * a.n_split), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_dw, dim3(dw_tiles(a.H, a.V) * a.n_split), dim3(256), 0, st, a);
 }
 
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st)
