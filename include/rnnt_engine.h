@@ -37,7 +37,8 @@ extern "C" {
 /* BASELINE config 3 ("bf16"): pointers stay fp32 at this boundary (inputs, parameters, costs,
  * gradients); the operands of the three GEMMs — tanh(enc+pred), W and the logits gradient —
  * are rounded to bf16 (nearest-even) and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation; logits, log-softmax, the lattice and every reduction stay fp32/fp64.  Fused
+ * accumulation; the logits are kept in fp16 (workspace only; nearest-even, the loss is computed
+ * from the stored values); log-softmax, the lattice and every reduction stay fp32/fp64.  Fused
  * entry only (rnnt_engine_joint_loss_fwd_bwd, rnnt_engine_run_stage, the workspace queries);
  * needs H % 128 == 0, H <= 512, V % 128 == 0. */
 #define RNNT_DTYPE_BF16 1

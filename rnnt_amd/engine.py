@@ -16,7 +16,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_CSRC, "librnnt_engine.so")
 
 DTYPE_F32 = 0
-DTYPE_BF16 = 1  # bf16 GEMM operands, fp32 accumulate / logits / loss; fp32 tensors at the boundary
+DTYPE_BF16 = 1  # bf16 GEMM operands, fp32 accumulate, fp16 logits (workspace), fp32/fp64 loss; fp32 tensors at the boundary
 _DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, DTYPE_F32: DTYPE_F32,
            "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, DTYPE_BF16: DTYPE_BF16}
 
