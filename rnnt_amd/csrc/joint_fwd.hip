@@ -642,16 +642,16 @@ template <bool WITH_LOSS, bool USE_HID, bool PAIRS, bool MAKE_HID, bool BREG>
 __global__ __launch_bounds__(FWD_THREADS, 2) void k_joint_fwd_persist(JointFwdArgs a, int ntx, int ntot)
 {
     __shared__ __attribute__((aligned(16))) char smem[FWD_SMEM(BREG)];
-    __shared__ int s_next;
-    if (threadIdx.x == 0) s_next = (int)atomicAdd(a.counter, 1u);
+    __shared__ int s_next[2];
+    if (threadIdx.x == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
     __syncthreads();
-    int t = s_next;
-    while (t < ntot) {
+    int t = s_next[0];
+    for (int it = 1; t < ntot; ++it) {
+        // the next tile is requested while this one is computed: the atomic's round trip is hidden
+        if (threadIdx.x == 0) s_next[it & 1] = (int)atomicAdd(a.counter, 1u);
         fwd_tile<WITH_LOSS, USE_HID, PAIRS, MAKE_HID, BREG>(a, t % ntx, t / ntx, ntx, smem);
-        __syncthreads();  // every wave done with the tile's LDS state (and with s_next)
-        if (threadIdx.x == 0) s_next = (int)atomicAdd(a.counter, 1u);
-        __syncthreads();
-        t = s_next;
+        __syncthreads();  // every wave done with the tile's LDS state; s_next[it & 1] visible
+        t = s_next[it & 1];
     }
 }
 
@@ -661,12 +661,17 @@ void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
     dim3 grid(tiles, a.B), block(FWD_THREADS);
     if (a.denom_s && a.hidden) {
         const bool pairs = ((a.H + 7) / 8) % 2 == 0;  // even number of 8-wide chunks: the two-register-set main loop
-        if (a.make_hidden && pairs && !(a.flags & 128)) {
+        if (pairs && !(a.flags & 128)) {
             const long ntot = (long)tiles * a.B;
             if (a.counter && !(a.flags & 256) && ntot < 0x7fffffffL) {
                 (void)hipMemsetAsync(a.counter, 0, 4, st);
                 const int nwg = (int)(ntot < 2L * a.n_cu ? ntot : 2L * a.n_cu);
-                hipLaunchKernelGGL((k_joint_fwd_persist<true, true, true, true, true>), dim3(nwg), block, 0, st, a, tiles, (int)ntot);
+                if (a.make_hidden)
+                    hipLaunchKernelGGL((k_joint_fwd_persist<true, true, true, true, true>), dim3(nwg), block, 0, st, a, tiles, (int)ntot);
+                else  // hidden comes from the separate k_make_hidden pass (rnnt_engine_set_flags(64))
+                    hipLaunchKernelGGL((k_joint_fwd_persist<true, true, true, false, true>), dim3(nwg), block, 0, st, a, tiles, (int)ntot);
+            } else if (!a.make_hidden) {
+                hipLaunchKernelGGL((k_joint_fwd<true, true, true, false, true>), grid, block, 0, st, a);
             } else {
                 hipLaunchKernelGGL((k_joint_fwd<true, true, true, true, true>), grid, block, 0, st, a);
             }

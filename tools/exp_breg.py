@@ -23,7 +23,7 @@ if __name__ == "__main__":
         e1.record(); e1.synchronize()
         return e0.elapsed_time(e1) / reps
     ref = None
-    for flags in (0, 256, 128, 0, 256, 128):
+    for flags in (0, 256, 0, 256):
         engine.lib().rnnt_engine_set_flags(flags)
         outs = [o.clone() for o in run()]
         if ref is None:
