@@ -262,6 +262,29 @@ def test_fused_path_is_bitwise_reproducible(amd):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("shape", [(3, 61, 23, 128, 260), (2, 300, 40, 512, 1024)])
+def test_forward_kernel_variants_agree_bitwise(amd, shape):
+    """The forward GEMM has switchable forms (rnnt_engine_set_flags): persistent workgroups with
+    register-streamed W fragments (default), 64: hidden from the separate k_make_hidden pass,
+    128: the LDS-DMA ring main loop, 256: one workgroup per tile.  They multiply the same numbers
+    in the same order, so every output must be identical bit for bit."""
+    B, T, U, H, V = shape
+    d = make_inputs(B, T, U, H, V, seed=21)
+    g = _dev(d)
+    lib = amd.engine.lib()
+    run = lambda: [o.clone() for o in amd.engine.joint_loss_fwd_bwd(
+        g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"], g["target_lens"],
+        V - 1, 1.0 / B)]
+    try:
+        ref = run()
+        for flags in (64, 128, 256, 64 | 256):
+            lib.rnnt_engine_set_flags(flags)
+            for x, y in zip(run(), ref):
+                assert torch.equal(x, y), flags
+    finally:
+        lib.rnnt_engine_set_flags(0)
+
+
 # ---------------------------------------------------------------- full-size properties
 def _full(amd, B, T, U, H, V, seed, dtype="fp32"):
     d = make_inputs(B, T, U, H, V, seed, ragged=False)
