@@ -95,7 +95,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
     L->slab_w = o;   o += align_up((size_t)L->n_split * V * H * 4);
     L->slab_b = o;   o += align_up((size_t)L->n_split * V * 4);
-    L->counters = o; o += 1024;
+    L->counters = o; o += 1024 + align_up((2 * (size_t)B + 2) * 8);  // + the dW live-row table
     L->total = o;
 }
 
@@ -182,7 +182,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
-    g.counter = (unsigned *)(ws + L.counters); g.n_cu = device_cus(); g.flags = g_flags & ~16; g.debug = g_debug;
+    g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = g_flags & ~16; g.debug = g_debug;
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;
         h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;

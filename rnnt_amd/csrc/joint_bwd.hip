@@ -744,6 +744,30 @@ void launch_make_g(const JointBwdArgs &a, hipStream_t st)
 #define DW_KC 16   // cells per split-range granule (row padding unit)
 #define DW_RING 8  // k-steps of operands in flight per wave
 
+// Live-row table of the dW GEMM.  K runs over lattice cells, but an utterance shorter than T only
+// has G != 0 in its first T_b*U1 cells: the K ranges of the splits are cut from the LIVE 16-cell
+// granules only, so a ragged batch costs what its lengths cost.  tab[b] = first granule of
+// utterance b's live range, tab[B+1+b] = live granules before it, tab[2B+1] = their total.  A
+// live range is rounded out to whole granules (the extra rows are cells of time step T_b, which
+// k_dhidden_gen zero-fills) and never overlaps the previous one.
+__global__ void k_dw_table(const int32_t *__restrict__ logit_lens, int B, int T, int U1, long *__restrict__ tab)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long prev_end = 0, cum = 0;
+    for (int b = 0; b < B; ++b) {
+        const long c0 = (long)b * T * U1;
+        long s = c0 / DW_KC, e = (c0 + (long)logit_lens[b] * U1 + DW_KC - 1) / DW_KC;
+        if (s < prev_end) s = prev_end;
+        if (e < s) e = s;
+        tab[b] = s;
+        tab[B + 1 + b] = cum;
+        cum += e - s;
+        prev_end = e;
+    }
+    tab[B] = prev_end;
+    tab[2 * B + 1] = cum;
+}
+
 // Workgroups per split: 2x2 blocks of 128x128 wave tiles (a 256x256 workgroup tile); when H has
 // an odd number of 128-column tiles (cfg4: H = 640) the last column is covered by 4x1 blocks
 // instead of a half-empty 256-wide tile (12 -> 10 workgroup tiles per split at cfg4).
@@ -778,9 +802,11 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
     const int v0 = vt * 128, h0 = ht * 128;
     const int vbase = v0 + 4 * i, hbase = h0 + 4 * i;
     const bool vok = vbase < V, hok = hbase < H;
-    const long nchunk = a.rows_pad / DW_KC;
-    const long k_lo = nchunk * split / a.n_split, k_hi = nchunk * (split + 1) / a.n_split;
-    const long nstep = (k_hi - k_lo) * (DW_KC / 2);  // k-steps (cell pairs); multiple of DW_RING
+    // this split's share of the LIVE granules (k_dw_table), walked utterance by utterance
+    const long *tab = a.dw_tab;
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -791,10 +817,18 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    if (nstep > 0) {  // workgroup-uniform
+    int ub = 0;
+    while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;  // utterance holding live granule g_lo
+    for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform
+        const long cum0 = tab[B + 1 + ub], cum1 = ub + 1 < B ? tab[B + 1 + ub + 1] : nlive;
+        const long ge = cum1 < g_hi ? cum1 : g_hi;  // end of this utterance's part (live index)
+        if (ge <= gq) continue;
+        const long k_lo = tab[ub] + (gq - cum0);     // actual first granule
+        const long nstep = (ge - gq) * (DW_KC / 2);  // k-steps (cell pairs); multiple of DW_RING
+        gq = ge;
         // columns beyond V / H (edge tiles) re-read the last valid 16 bytes: they only feed
-        // accumulators that are never stored.  The buffers carry DW_KC extra zero rows, so the
-        // ring may run DW_RING k-steps past the end of the last split.
+        // accumulators that are never stored.  The buffers carry DW_KC extra rows, so the
+        // ring may run DW_RING k-steps past the end of a range (loaded, never multiplied).
         const float *gp = a.logits + (k_lo * DW_KC + half) * (long)V + (vok ? vbase : V - 4);
         const float *hp = a.hidden + (k_lo * DW_KC + half) * (long)H + (hok ? hbase : H - 4);
         const long gstep = 2L * V, hstep = 2L * H;
@@ -883,6 +917,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ 
 
 void launch_dw(const JointBwdArgs &a, hipStream_t st)
 {
+    hipLaunchKernelGGL(k_dw_table, dim3(1), dim3(64), 0, st, a.logit_lens, a.B, a.T, a.U1, a.dw_tab);
     hipLaunchKernelGGL(k_dw, dim3(dw_tiles(a.H, a.V) * a.n_split), dim3(256), 0, st, a);
 }
 

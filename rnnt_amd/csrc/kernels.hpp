@@ -60,6 +60,7 @@ struct JointBwdArgs {
     int B, T, U1, H, V, blank;
     int n_ublk, n_ttile, n_split;
     unsigned *counter;  // 8 x 64 zeroed bytes: per-XCD work-item counters of the persistent kernels
+    long *dw_tab;       // 2B+2 longs: live-row table of k_dw (k_dw_table)
     int n_cu;           // compute units (grid size of the persistent kernels)
     int flags;          // bit 4 (16): G is produced by k_dhidden_gen; others: experiment switches
     unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
