@@ -269,6 +269,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     float *lptr = (float *)a.logits + pcell * V + 4 * half;
 
     if (t0 >= Tb) {  // workgroup-uniform: nothing to multiply, but k_dw must find zeros here
+        // k_dw only walks the live rows, rounded out to 16-cell granules (k_dw_table): past an
+        // utterance's end that reaches into time step T_b (this tile if t0 == T_b rounded up to the
+        // tile size) and, before the next utterance's first granule, into the last time step
+        if (t0 >= Tb + DG_BT && t0 + DG_BT < T) return;
         if (pexists) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;
