@@ -248,6 +248,16 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
     const int H = a.H, V = a.V, KC = H / 32;
     const int npass = (V + 255) / 256;
     const long NC = (long)npass * KC;
+    {   // tiles with no live cell: the row padding past the last cell, and tiles that lie entirely
+        // in the dead time steps (t >= T_b) of one utterance — their logits are never read
+        // (k_dhidden_bf16 zero-fills the G rows of dead tiles itself)
+        const long cells = (long)a.B * a.T * a.U1, per = (long)a.T * a.U1;
+        const long c_first = (long)blockIdx.x * 128, c_last = c_first + 127;
+        if (c_first >= cells) return;
+        const long b_first = c_first / per;
+        if (c_last < cells && c_last / per == b_first &&
+            (c_first - b_first * per) / a.U1 >= a.logit_lens[b_first]) return;
+    }
     const long row0 = (long)blockIdx.x * 128 + wave * 32;
     const u32x4 *ap = (const u32x4 *)(a.hidden + (row0 + j) * H) + 2 * half;  // chunk c: ap[4c], ap[4c+1]
     const u32x4 *wp = (const u32x4 *)a.wpack_fwd;
@@ -687,9 +697,11 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
     }
     const int tile = id % tiles, split = id / tiles;
     const int vb = tile / n_hblk, hb = tile % n_hblk;
-    const long nstage_all = a.rows_pad / BW_ROWS;
-    const long k_lo = nstage_all * split / a.n_split, k_hi = nstage_all * (split + 1) / a.n_split;
-    const long nstage = k_hi - k_lo;
+    // this split's share of the LIVE 32-cell stages (k_dw_table): a ragged batch costs its lengths
+    const long *tab = a.dw_tab;
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -704,14 +716,14 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
     float dbl[4] = {0.f, 0.f, 0.f, 0.f};
     const unsigned one_pair_u = 0x3f803f80u;  // (1.0bf16, 1.0bf16)
 
-    if (nstage > 0) {
+    if (g_hi > g_lo) {
         // ---- DMA source of this wave's operand tile: wave 0/1 -> G column halves, 2/3 -> hidden
         const bool is_g = wave < 2;
         int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
         if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
         const long rstride = is_g ? 2L * V : 2L * H;  // bytes between cells
-        const char *src = (is_g ? (const char *)a.logits : (const char *)a.hidden) +
-                          (k_lo * BW_ROWS) * rstride + 2L * col0;
+        const char *src0 = (is_g ? (const char *)a.logits : (const char *)a.hidden) + 2L * col0;
+        const char *src = src0;  // + the first row of the range being walked
         // DMA i (0..7) of a stage: rows 4i .. 4i+3; lane L: row 4i + (L>>4), LDS chunk position L&15
         // <- global chunk (L&15) ^ swz(row), swz = ((L>>4)<<2) | (i&3)
         int soff[8];
@@ -801,6 +813,15 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             }
         };
 
+        int ub = 0;
+        while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;  // utterance holding live stage g_lo
+        for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
+        const long cum0 = tab[B + 1 + ub], cum1 = ub + 1 < B ? tab[B + 1 + ub + 1] : nlive;
+        const long ge = cum1 < g_hi ? cum1 : g_hi;
+        if (ge <= gq) continue;
+        const long nstage = ge - gq;
+        src = src0 + ((tab[ub] + (gq - cum0)) * BW_ROWS) * rstride;
+        gq = ge;
         // Pipeline.  B_s = barrier publishing stage s (every wave has landed its share and has
         // finished reading stage s-1).  After B_s: reads of stage s, DMA of stage s+3 into the
         // slot of stage s-1.  Fragment reads run one k-step ahead of their MFMAs.
@@ -824,7 +845,9 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             mma_step(Y, st + 3, (slot + 3) & 3, 4);
             landed(X, true);  // X is loop-carried: landed before the back-edge, copies are safe
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before exit
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the
+        lds_barrier();                                     // ring is refilled / the kernel exits
+        }
     }
 
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r
@@ -856,6 +879,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 
 void launch_dw_bf16(const Bf16Args &a, hipStream_t st)
 {
+    launch_dw_table(a.logit_lens, a.B, a.T, a.U1, BW_ROWS, a.dw_tab, st);
     const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per process
     if (!attr_set) {

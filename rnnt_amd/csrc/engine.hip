@@ -196,6 +196,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         h.rows_pad = (long)L.rows_pad; h.rows_alloc = bf16_rows_alloc(L.rows_pad);
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
         h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = g_flags;
+        h.dw_tab = (long *)(ws + L.counters + 1024);
         g.flags |= 16;  // reductions: dPred slabs are 8 t-rows high, as in k_dhidden_gen
         if (stages & ST_PROD) launch_bf16_producers(h, st);
         if (stages & ST_FWD) launch_joint_fwd_bf16(h, st);  // softmax statistics in its epilogue

@@ -749,18 +749,18 @@ void launch_make_g(const JointBwdArgs &a, hipStream_t st)
 #define DW_RING 8  // k-steps of operands in flight per wave
 
 // Live-row table of the dW GEMM.  K runs over lattice cells, but an utterance shorter than T only
-// has G != 0 in its first T_b*U1 cells: the K ranges of the splits are cut from the LIVE 16-cell
-// granules only, so a ragged batch costs what its lengths cost.  tab[b] = first granule of
+// has G != 0 in its first T_b*U1 cells: the K ranges of the splits are cut from the LIVE granules
+// (16 cells here, 32 on the bf16 route) only, so a ragged batch costs what its lengths cost.  tab[b] = first granule of
 // utterance b's live range, tab[B+1+b] = live granules before it, tab[2B+1] = their total.  A
 // live range is rounded out to whole granules (the extra rows are cells of time step T_b, which
 // k_dhidden_gen zero-fills) and never overlaps the previous one.
-__global__ void k_dw_table(const int32_t *__restrict__ logit_lens, int B, int T, int U1, long *__restrict__ tab)
+__global__ void k_dw_table(const int32_t *__restrict__ logit_lens, int B, int T, int U1, int gran, long *__restrict__ tab)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long prev_end = 0, cum = 0;
     for (int b = 0; b < B; ++b) {
         const long c0 = (long)b * T * U1;
-        long s = c0 / DW_KC, e = (c0 + (long)logit_lens[b] * U1 + DW_KC - 1) / DW_KC;
+        long s = c0 / gran, e = (c0 + (long)logit_lens[b] * U1 + gran - 1) / gran;
         if (s < prev_end) s = prev_end;
         if (e < s) e = s;
         tab[b] = s;
@@ -775,6 +775,11 @@ __global__ void k_dw_table(const int32_t *__restrict__ logit_lens, int B, int T,
 // Workgroups per split: 2x2 blocks of 128x128 wave tiles (a 256x256 workgroup tile); when H has
 // an odd number of 128-column tiles (cfg4: H = 640) the last column is covered by 4x1 blocks
 // instead of a half-empty 256-wide tile (12 -> 10 workgroup tiles per split at cfg4).
+void launch_dw_table(const int32_t *logit_lens, int B, int T, int U1, int gran, long *tab, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dw_table, dim3(1), dim3(64), 0, st, logit_lens, B, T, U1, gran, tab);
+}
+
 int dw_tiles(int H, int V)
 {
     const int nv = (V + 127) / 128, nh = (H + 127) / 128;
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ 
 
 void launch_dw(const JointBwdArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_dw_table, dim3(1), dim3(64), 0, st, a.logit_lens, a.B, a.T, a.U1, a.dw_tab);
+    launch_dw_table(a.logit_lens, a.B, a.T, a.U1, DW_KC, a.dw_tab, st);
     hipLaunchKernelGGL(k_dw, dim3(dw_tiles(a.H, a.V) * a.n_split), dim3(256), 0, st, a);
 }
 

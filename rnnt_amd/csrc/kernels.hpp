@@ -68,6 +68,7 @@ struct JointBwdArgs {
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);
 int dw_tiles(int H, int V);  // workgroup tiles per split of k_dw
+void launch_dw_table(const int32_t *logit_lens, int B, int T, int U1, int gran, long *tab, hipStream_t st);
 void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
@@ -93,6 +94,7 @@ struct Bf16Args {
     int B, T, U1, H, V, blank;
     int n_ublk, n_split;
     int flags;  // experiment switches (bits 8..: 256 no stores, 512 no statistics, 1024 no MFMA)
+    long *dw_tab;  // 2B+2 longs: live-row table of k_dw_bf16 (k_dw_table, 32-cell granules)
 };
 size_t bf16_wpack_fwd_bytes(int H, int V);
 size_t bf16_wpack_dh_bytes(int V);

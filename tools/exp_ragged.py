@@ -8,6 +8,7 @@ import bench
 
 if __name__ == "__main__":
     dev = torch.device("cuda", 0)
+    dtype = sys.argv[1] if len(sys.argv) > 1 else "fp32"
     B, T, U, H, V = bench.CONFIGS["cfg2"]
     enc, pred, W, bias, targets, ll, tl = bench.synth(B, T, U, H, V, 1234, dev)
     g = torch.Generator().manual_seed(7)
@@ -17,7 +18,7 @@ if __name__ == "__main__":
     for tag, l1, l2 in (("full", ll, tl), ("ragged", ll_r.to(dev), tl_r.to(dev))):
         def run(stage=None):
             kw = {} if stage is None else {"stage": stage}
-            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, l1, l2, V - 1, 1.0 / 32, **kw)
+            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, l1, l2, V - 1, 1.0 / 32, dtype=dtype, **kw)
         def timed(stage=None, reps=5):
             run(stage); run(stage)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
