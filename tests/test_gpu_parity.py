@@ -66,6 +66,37 @@ def test_fused_joint_loss_vs_oracle(amd, shape):
     _compare(_run_fused(amd, d), oracle_fused(d))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_very_ragged_batch_vs_oracle(amd, dtype):
+    """Utterances of 1, 2 and a few time steps next to a full one, empty and full targets: the dW
+    GEMM walks only the live rows (k_dw_table: ranges rounded out to 16/32-cell granules, merged
+    where they touch), dead forward / dHidden tiles are skipped or zero-filled.  T*U1 = 37*11 is
+    odd, so every utterance starts in the middle of a granule."""
+    B, T, U, H, V = 6, 37, 10, 128, 128
+    d = make_inputs(B, T, U, H, V, seed=77)
+    d["logit_lens"] = np.array([37, 1, 2, 9, 36, 17], dtype=np.int32)
+    d["target_lens"] = np.array([10, 0, 1, 10, 0, 5], dtype=np.int32)
+    r = _run_fused(amd, d, dtype=dtype)
+    if dtype == "fp32":
+        _compare(r, oracle_fused(d))
+    else:
+        ref = oracle_fused_bf16(d)
+        assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)
+        for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+            assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL)
+    # twice on the same workspace: rows the first call left behind must not leak into the second
+    d2 = dict(d)
+    d2["logit_lens"] = np.array([3, 37, 30, 1, 1, 37], dtype=np.int32)
+    d2["target_lens"] = np.array([2, 10, 0, 0, 10, 3], dtype=np.int32)
+    r2 = _run_fused(amd, d2, dtype=dtype)
+    if dtype == "fp32":
+        _compare(r2, oracle_fused(d2))
+    else:
+        ref2 = oracle_fused_bf16(d2)
+        for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+            assert_close_grad(k, r2[k], ref2[k], rtol=BF16_GRAD_RTOL)
+
+
 def test_fused_config1_plumbing_shape_vs_oracle(amd):
     """BASELINE.json configs[0]'s shape (B=2, T~200, U~50, H=1024, V=1024): H > 512 takes the
     persistent dHidden kernel + k_make_g route."""
