@@ -437,7 +437,9 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     unsigned short *lrow = a.logits + pcell * V;
     u32x4 *grow = (u32x4 *)lrow + qd;  // chunk c: grow[4c]  (16 B of bf16 at byte 64c + 16qd)
 
-    if (t0 >= Tb) {  // workgroup-uniform: no products, but k_dw_bf16 must find zeros here
+    // workgroup-uniform: no products past the utterance's length or in a u block past U_b (no
+    // lattice cell; the reductions skip its slabs), but k_dw_bf16 must find zeros in these rows
+    if (t0 >= Tb || u0 > a.target_lens[b]) {
         if (pexists) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int c = 0; c < VC; ++c) grow[4 * c] = z;

@@ -174,7 +174,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
 
     JointBwdArgs g;
     g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred;
-    g.W = (const float *)W; g.logits = logits; g.coef = coef; g.logit_lens = logit_lens;
+    g.W = (const float *)W; g.logits = logits; g.coef = coef; g.logit_lens = logit_lens; g.target_lens = target_lens;
     g.hidden = (float *)(ws + L.hidden); g.rows_pad = (long)L.rows_pad;
     g.slab_enc = (float *)(ws + L.slab_enc); g.slab_pred = (float *)(ws + L.slab_pred);
     g.slab_w = (float *)(ws + L.slab_w); g.slab_b = (float *)(ws + L.slab_b);

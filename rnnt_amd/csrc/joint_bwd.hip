@@ -279,6 +279,13 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         }
         return;
     }
+    if (u0 > a.target_lens[b]) {  // workgroup-uniform: a u block past U_b holds no lattice cell — its G
+        if (pexists) {  // rows are zeros (k_dw walks them), its slabs are never read
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;
+        }
+        return;
+    }
     GSTAMP(0);
 
     CellCoef cf = a.coef[pexists ? pcell : 0];
@@ -597,6 +604,7 @@ bool dhidden_gen_ok(int H, int V) { return H <= 512 && (V % 32) == 0; }
 // out[b,t,:] = sum_ub slab_enc[ub][b,t,:]  (0 for t >= T_b)
 __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ slab,
                                                     const int32_t *__restrict__ logit_lens,
+                                                    const int32_t *__restrict__ target_lens,
                                                     float *__restrict__ out, int B, int T, int H,
                                                     int n_ublk)
 {
@@ -607,14 +615,20 @@ __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ sl
     const long bt = idx / H4;
     const int t = (int)(bt % T), b = (int)(bt / T);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (t < logit_lens[b])
-        for (int k = 0; k < n_ublk; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
+    if (t < logit_lens[b]) {
+        // u blocks that start past U_b hold no lattice cell; the fused dHidden kernels skip them
+        // without writing their slab
+        int nub = target_lens[b] / DH_BU + 1;
+        if (nub > n_ublk) nub = n_ublk;
+        for (int k = 0; k < nub; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
+    }
     ((f32x4 *)out)[idx] = s;
 }
 
 // out[b,u,:] = sum_{tt < ceil(T_b/8)} slab_pred[tt][b,u,:]
 __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ slab,
                                                      const int32_t *__restrict__ logit_lens,
+                                                     const int32_t *__restrict__ target_lens,
                                                      float *__restrict__ out, int B, int U1, int H,
                                                      int bt)
 {
@@ -624,8 +638,10 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ s
     if (idx >= n) return;
     const int b = (int)(idx / ((long)U1 * H4));
     const int ntt = (logit_lens[b] + bt - 1) / bt;  // slabs written: t tiles of height bt
+    const int u = (int)((idx / H4) % U1);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < ntt; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
+    if (u <= target_lens[b])  // rows past U_b: no lattice cell, and their u block may not have been written
+        for (int k = 0; k < ntt; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
     ((f32x4 *)out)[idx] = s;
 }
 
@@ -647,10 +663,10 @@ void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)
 {
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,
-                       a.slab_enc, a.logit_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);
+                       a.slab_enc, a.logit_lens, a.target_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);
     const long n4p = (long)a.B * a.U1 * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_pred, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st,
-                       a.slab_pred, a.logit_lens, a.grad_pred, a.B, a.U1, a.H,
+                       a.slab_pred, a.logit_lens, a.target_lens, a.grad_pred, a.B, a.U1, a.H,
                        (a.flags & 16) ? DG_BT : PW_BT);
 }
 

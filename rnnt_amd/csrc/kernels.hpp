@@ -51,7 +51,7 @@ struct JointBwdArgs {
     float *hidden;        // [rows_pad,H] tanh(enc+pred) (k_make_hidden)
     long rows_pad;        // B*T*U1 rounded up to a multiple of 16 (zero rows)
     const CellCoef *coef; // [B,T,U1]
-    const int32_t *logit_lens;
+    const int32_t *logit_lens, *target_lens;
     float *slab_enc;   // [n_ublk][B,T,H]
     float *slab_pred;  // [n_ttile][B,U1,H]
     float *slab_w;     // [n_split][V,H]
