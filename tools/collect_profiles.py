@@ -62,8 +62,8 @@ for key, (dt, ks) in names.items():
     out[key] = {}
     for stage, kn in ks.items():
         if kn == "k_dw":
-            fk = {k: v for k, v in f.items() if k.startswith("k_dw") and "bf16" not in k}
-            wk = {k: v for k, v in w.items() if k.startswith("k_dw") and "bf16" not in k}
+            fk = {k: v for k, v in f.items() if k == "k_dw"}
+            wk = {k: v for k, v in w.items() if k == "k_dw"}
             fr, wr = pick(fk, "k_dw"), pick(wk, "k_dw")
         else:
             fr, wr = pick(f, kn), pick(w, kn)
