@@ -267,44 +267,52 @@ __device__ __forceinline__ void lattice_chain(
         if (st_ok) out[(long)d * U1 + u] = prev;
         publish(0, prev);
     }
-    float lbr[LAT_PF], ler[LAT_PF];
-#pragma unroll
-    for (int q = 0; q < LAT_PF; ++q) fetch(1 + q, lbr[q], ler[q]);
     // mailbox of step k-1, requested one step early
     int tg = 0;
     double bv = NINF;
     if (has_cons) { tg = mtag[cb]; bv = mval[cb]; }
-    for (int k0 = 1; k0 < nd; k0 += LAT_PF) {
-#pragma unroll
-        for (int q = 0; q < LAT_PF; ++q) {
-            const int k = k0 + q;
-            if (k < nd) {  // workgroup-uniform
-                const int d = DIR == 0 ? k : nd - 1 - k;
-                if (has_cons) {  // wave-uniform
-                    for (int spin = 0; tg != k && spin < (1 << 22); ++spin) { tg = mtag[cb + k - 1]; bv = mval[cb + k - 1]; }
-                }
-                // neighbour column of the previous diagonal: u-1 (alpha) / u+1 (beta); the lane at
-                // the wave's edge keeps the mailbox value (-inf at the lattice's edge)
-                const double nb = DIR == 0 ? wave_shift<0x138>(prev, bv) : wave_shift<0x130>(prev, bv);
-                if (has_cons && k + 1 < nd) { tg = mtag[cb + k]; bv = mval[cb + k]; }  // next step's, early
-                float lb = lbr[q], le = ler[q];
-                asm("v_min_f32 %0, 0, %0" : "+v"(lb));  // plain min: fminf() adds a canonicalising v_max
-                asm("v_min_f32 %0, 0, %0" : "+v"(le));
-                const double a = prev + (double)lb;
-                const double e = nb + (double)le;
-                // log(exp(a) + exp(e)) = max + log(1 + exp(-|a - e|)); the correction is < ln 2 and
-                // evaluated in fp32 with the hardware exp2/log2.  A cell of the lattice has at
-                // least one finite predecessor; everything else is overwritten by the select.
-                const float dl = -fabsf((float)(a - e));
-                const double v = fmax(a, e) +
-                    (double)(__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(dl * RNNT_LOG2E)) * 0.6931471805599453f);
-                const bool valid = (unsigned)(d - ukey) < (unsigned)Tb;
-                prev = valid ? v : NINF;
-                publish(k, prev);
-                if (st_ok) out[(long)d * U1 + u] = prev;
-            }
-            fetch(k + LAT_PF, lbr[q], ler[q]);
+    auto step = [&](int k, float lb, float le) {
+        const int d = DIR == 0 ? k : nd - 1 - k;
+        if (has_cons && tg != k) {  // wave-uniform; rare once the waves have settled a step apart
+            for (int spin = 0; tg != k && spin < (1 << 22); ++spin) { tg = mtag[cb + k - 1]; bv = mval[cb + k - 1]; }
         }
+        // neighbour column of the previous diagonal: u-1 (alpha) / u+1 (beta); the lane at the
+        // wave's edge keeps the mailbox value (-inf at the lattice's edge)
+        const double nb = DIR == 0 ? wave_shift<0x138>(prev, bv) : wave_shift<0x130>(prev, bv);
+        if (has_cons) { tg = mtag[cb + k]; bv = mval[cb + k]; }  // next step's, early (slot k < D always exists)
+        asm("v_min_f32 %0, 0, %0" : "+v"(lb));  // plain min: fminf() adds a canonicalising v_max
+        asm("v_min_f32 %0, 0, %0" : "+v"(le));
+        const double a = prev + (double)lb;
+        const double e = nb + (double)le;
+        // log(exp(a) + exp(e)) = max + log(1 + exp(-|a - e|)); the correction is < ln 2 and
+        // evaluated in fp32 with the hardware exp2/log2.  A cell of the lattice has at least one
+        // finite predecessor; everything else is overwritten by the select.
+        const float dl = -fabsf((float)(a - e));
+        const double v = fmax(a, e) +
+            (double)(__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(dl * RNNT_LOG2E)) * 0.6931471805599453f);
+        const bool valid = (unsigned)(d - ukey) < (unsigned)Tb;
+        prev = valid ? v : NINF;
+        publish(k, prev);
+        if (st_ok) out[(long)d * U1 + u] = prev;
+    };
+    // full blocks of LAT_PF steps with the lp values prefetched one block ahead, then the tail
+    float lbr[LAT_PF], ler[LAT_PF];
+    int k0 = 1;
+    if (nd - 1 >= LAT_PF) {
+#pragma unroll
+        for (int q = 0; q < LAT_PF; ++q) fetch(1 + q, lbr[q], ler[q]);
+        for (; k0 + LAT_PF <= nd; k0 += LAT_PF) {
+#pragma unroll
+            for (int q = 0; q < LAT_PF; ++q) {
+                step(k0 + q, lbr[q], ler[q]);
+                fetch(k0 + q + LAT_PF, lbr[q], ler[q]);  // clamped to the last diagonal inside
+            }
+        }
+    }
+    for (; k0 < nd; ++k0) {
+        float lb, le;
+        fetch(k0, lb, le);
+        step(k0, lb, le);
     }
     if (DIR == 1 && u == 0) costs[b] = (float)(-prev);  // -beta[0,0]
 }
