@@ -27,6 +27,7 @@
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 
 #define DH_BT 8
+#define DW_KC 16   // cells per dW split-range granule (row padding unit)
 #define DH_BU 16
 
 // dHidden GEMM: dHidden[c,:] = G[c,:] @ W   (K = V), then dPre = dHidden * (1 - hidden^2)
@@ -269,10 +270,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     float *lptr = (float *)a.logits + pcell * V + 4 * half;
 
     if (t0 >= Tb) {  // workgroup-uniform: nothing to multiply, but k_dw must find zeros here
-        // k_dw only walks the live rows, rounded out to 16-cell granules (k_dw_table): past an
-        // utterance's end that reaches into time step T_b (this tile if t0 == T_b rounded up to the
-        // tile size) and, before the next utterance's first granule, into the last time step
-        if (t0 >= Tb + DG_BT && t0 + DG_BT < T) return;
+        // k_dw only walks the live rows, rounded out to 16-cell granules (k_dw_table): up to 15
+        // cells past this utterance's live end, and up to 15 cells before the next utterance's
+        // first cell (= the last cells of this one).  Tiles that touch neither stay unwritten.
+        if ((long)t0 * U1 >= (long)Tb * U1 + DW_KC && (long)(t0 + DG_BT) * U1 <= (long)T * U1 - DW_KC) return;
         if (pexists) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;
@@ -761,7 +762,6 @@ void launch_make_g(const JointBwdArgs &a, hipStream_t st)
 // (same wm or same wn) run in step and meet in L1/L2.
 // The grid is 1-D and XCD-aware: the tiles of one split (same cells, different v/h blocks)
 // get consecutive remapped ids and therefore share an XCD's L2.
-#define DW_KC 16   // cells per split-range granule (row padding unit)
 #define DW_RING 8  // k-steps of operands in flight per wave
 
 // Live-row table of the dW GEMM.  K runs over lattice cells, but an utterance shorter than T only

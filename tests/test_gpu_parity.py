@@ -97,6 +97,42 @@ def test_fused_very_ragged_batch_vs_oracle(amd, dtype, H):
             assert_close_grad(k, r2[k], ref2[k], rtol=BF16_GRAD_RTOL)
 
 
+def _random_case(rng, bf16):
+    B = int(rng.integers(1, 6)); T = int(rng.integers(1, 70)); U = int(rng.integers(0, 40))
+    if bf16:
+        H = int(rng.choice([128, 256, 384, 512])); V = int(rng.choice([128, 256, 384]))
+    else:
+        H = 4 * int(rng.integers(1, 161)); V = 4 * int(rng.integers(1, 80))
+    d = make_inputs(B, T, U, H, V, seed=int(rng.integers(1 << 30)))
+    ll = rng.integers(1, T + 1, B); tl = rng.integers(0, U + 1, B)
+    ll[rng.integers(B)] = T; tl[rng.integers(B)] = U
+    d["logit_lens"] = ll.astype(np.int32); d["target_lens"] = tl.astype(np.int32)
+    return d
+
+
+def test_fused_random_shapes_and_lengths_vs_oracle(amd):
+    """Seeded sweep (tools/fuzz_parity.py runs the long version): random shapes with arbitrary
+    lengths per utterance.  First the case that sweep found: T*U1 = 205 cells per utterance, short
+    utterances — the dW granule of the NEXT utterance's first cell reaches back into dead time
+    steps of this one that no dHidden tile had zero-filled."""
+    d = make_inputs(5, 41, 4, 480, 192, seed=5)
+    d["logit_lens"] = np.array([20, 8, 41, 19, 28], dtype=np.int32)
+    d["target_lens"] = np.array([1, 4, 0, 4, 3], dtype=np.int32)
+    _compare(_run_fused(amd, d), oracle_fused(d))
+    rng = np.random.default_rng(31337)
+    for it in range(24):
+        bf = it % 4 == 3
+        d = _random_case(rng, bf)
+        r = _run_fused(amd, d, dtype="bf16" if bf else "fp32")
+        if bf:
+            ref = oracle_fused_bf16(d)
+            assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)
+            for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+                assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL)
+        else:
+            _compare(r, oracle_fused(d))
+
+
 def test_fused_config1_plumbing_shape_vs_oracle(amd):
     """BASELINE.json configs[0]'s shape (B=2, T~200, U~50, H=1024, V=1024): H > 512 takes the
     persistent dHidden kernel + k_make_g route."""

@@ -1,0 +1,59 @@
+"""Randomised parity sweep on the GPU: random (B,T,U,H,V) and arbitrary ragged lengths (1-step
+utterances, empty targets) through the fused path against the fp64 oracle (fp32 route) / the
+rounding-point oracle (bf16 route), with the tolerances of tests/helpers.py.
+   python tools/fuzz_parity.py [n_fp32] [n_bf16] [seed]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+import rnnt_amd as amd
+from helpers import (make_inputs, oracle_fused, oracle_fused_bf16, assert_close_grad, assert_close_loss,
+                     BF16_LOSS_RTOL, BF16_GRAD_RTOL)
+
+
+def run(d, dtype):
+    g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    enc = g["enc"].requires_grad_(True); pred = g["pred"].requires_grad_(True)
+    W = g["W"].requires_grad_(True); bias = g["bias"].requires_grad_(True)
+    loss, costs = amd.joint_rnnt_loss(enc, pred, W, bias, g["targets"], g["logit_lens"], g["target_lens"],
+                                      blank=-1, reduction="mean", return_costs=True, dtype=dtype)
+    loss.backward()
+    return dict(loss=loss.item(), costs=costs.detach().cpu().numpy(), grad_enc=enc.grad.cpu().numpy(),
+                grad_pred=pred.grad.cpu().numpy(), grad_W=W.grad.cpu().numpy(), grad_bias=bias.grad.cpu().numpy())
+
+
+if __name__ == "__main__":
+    n32 = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    n16 = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2024)
+    bad = 0
+    for it in range(n32 + n16):
+        bf = it >= n32
+        B = int(rng.integers(1, 6)); T = int(rng.integers(1, 70)); U = int(rng.integers(0, 40))
+        if bf:
+            H = int(rng.choice([128, 256, 384, 512])); V = int(rng.choice([128, 256, 384]))
+        else:
+            H = 4 * int(rng.integers(1, 161)); V = 4 * int(rng.integers(1, 80))
+        d = make_inputs(B, T, U, H, V, seed=int(rng.integers(1 << 30)))
+        ll = rng.integers(1, T + 1, B); tl = rng.integers(0, U + 1, B)
+        ll[rng.integers(B)] = T; tl[rng.integers(B)] = U
+        d["logit_lens"] = ll.astype(np.int32); d["target_lens"] = tl.astype(np.int32)
+        tag = f"{'bf16' if bf else 'fp32'} B={B} T={T} U={U} H={H} V={V} ll={ll.tolist()} tl={tl.tolist()}"
+        try:
+            r = run(d, "bf16" if bf else "fp32")
+            ref = oracle_fused_bf16(d) if bf else oracle_fused(d)
+            if bf:
+                assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)
+                for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+                    assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL)
+            else:
+                assert_close_loss("costs", r["costs"], ref["costs"])
+                for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+                    assert_close_grad(k, r[k], ref[k])
+            print("ok  ", tag, flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("FAIL", tag, "::", str(e)[:300], flush=True)
+    print("failures:", bad)
+    sys.exit(1 if bad else 0)
