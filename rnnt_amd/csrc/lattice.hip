@@ -280,8 +280,11 @@ __device__ __forceinline__ void lattice_chain(
         // wave's edge keeps the mailbox value (-inf at the lattice's edge)
         const double nb = DIR == 0 ? wave_shift<0x138>(prev, bv) : wave_shift<0x130>(prev, bv);
         if (has_cons) { tg = mtag[cb + k]; bv = mval[cb + k]; }  // next step's, early (slot k < D always exists)
-        asm("v_min_f32 %0, 0, %0" : "+v"(lb));  // plain min: fminf() adds a canonicalising v_max
-        asm("v_min_f32 %0, 0, %0" : "+v"(le));
+        // fminf, not a bare v_min_f32: in IEEE mode the instruction turns a SIGNALLING NaN into a
+        // quiet NaN result, and slots of the lp arrays that no kernel wrote may hold any bit pattern
+        // (found by tools/fuzz_lattice.py); fminf canonicalises first (v_max x,x) and then returns 0
+        lb = fminf(lb, 0.f);
+        le = fminf(le, 0.f);
         const double a = prev + (double)lb;
         const double e = nb + (double)le;
         // log(exp(a) + exp(e)) = max + log(1 + exp(-|a - e|)); the correction is < ln 2 and

@@ -133,6 +133,51 @@ def test_fused_random_shapes_and_lengths_vs_oracle(amd):
             _compare(r, oracle_fused(d))
 
 
+@pytest.mark.parametrize("pattern", [0x7FA00000, 0xFFFFFFFF, 0x7F800000])
+def test_poisoned_workspace_does_not_leak(amd, pattern):
+    """The workspace is caller-owned scratch: whatever it holds (signalling NaNs, quiet NaNs, +inf)
+    must not reach a result.  Slots no kernel writes (lattice arrays outside the lattice, logits /
+    G / slabs of skipped tiles) are only ever dropped by a select or a range check — a bare
+    v_min_f32 let a signalling NaN through once (tools/fuzz_lattice.py)."""
+    from oracle import cpu_oracle
+    dev = torch.device("cuda", 0)
+
+    def poison():
+        ws = amd.engine.workspace(dev, 1)
+        ws.view(torch.int32)[: ws.numel() // 4].fill_(pattern - (1 << 32) if pattern >= (1 << 31) else pattern)
+
+    rng = np.random.default_rng(3)
+    for dtype, (B, T, U, H, V) in (("fp32", (3, 41, 13, 136, 68)), ("fp32", (2, 30, 9, 640, 64)),
+                                   ("bf16", (3, 41, 13, 128, 128))):
+        d = make_inputs(B, T, U, H, V, seed=pattern & 0xffff)
+        d["logit_lens"] = np.array(([T, 7, 23] if B == 3 else [11, T]), dtype=np.int32)
+        d["target_lens"] = np.array(([4, U, 0] if B == 3 else [U, 2]), dtype=np.int32)
+        _run_fused(amd, d, dtype=dtype)  # sizes the workspace
+        poison()
+        r = _run_fused(amd, d, dtype=dtype)
+        if dtype == "fp32":
+            _compare(r, oracle_fused(d))
+        else:
+            ref = oracle_fused_bf16(d)
+            assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)
+            for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+                assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL)
+    # standalone loss, wide lattice (five chained waves), utterances shorter than the batch
+    B, T, U, V = 3, 60, 300, 4
+    logits = (rng.standard_normal((B, T, U + 1, V)) * 2).astype(np.float32)
+    targets = rng.integers(0, V - 1, (B, U)).astype(np.int32)
+    ll = np.array([31, 60, 44], dtype=np.int32); tl = np.array([300, 280, 190], dtype=np.int32)
+    args = (torch.from_numpy(targets).cuda(), torch.from_numpy(ll).cuda(), torch.from_numpy(tl).cuda())
+    lt = torch.from_numpy(logits).cuda().requires_grad_(True)
+    amd.rnnt_loss(lt, *args, blank=-1, reduction="none")
+    poison()
+    costs = amd.rnnt_loss(lt, *args, blank=-1, reduction="none")
+    costs.sum().backward()
+    ref_c, ref_g = cpu_oracle.rnnt_loss(logits, targets, ll, tl)
+    assert_close_loss("costs", costs.detach().cpu().numpy(), ref_c)
+    assert_close_grad("grad_logits", lt.grad.cpu().numpy(), ref_g)
+
+
 def test_fused_config1_plumbing_shape_vs_oracle(amd):
     """BASELINE.json configs[0]'s shape (B=2, T~200, U~50, H=1024, V=1024): H > 512 takes the
     persistent dHidden kernel + k_make_g route."""
