@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU: random (B,T,U,H,V) and arbitrary ragged lengths (1-step
 utterances, empty targets) through the fused path against the fp64 oracle (fp32 route) / the
 rounding-point oracle (bf16 route), with the tolerances of tests/helpers.py.
-   python tools/fuzz_parity.py [n_fp32] [n_bf16] [seed]"""
+   python tools/fuzz_parity.py [n_fp32] [n_bf16] [seed] [max_H/4] [max_V/4]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -27,14 +27,16 @@ if __name__ == "__main__":
     n32 = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     n16 = int(sys.argv[2]) if len(sys.argv) > 2 else 15
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2024)
+    maxh = int(sys.argv[4]) if len(sys.argv) > 4 else 160
+    maxv = int(sys.argv[5]) if len(sys.argv) > 5 else 79
     bad = 0
     for it in range(n32 + n16):
         bf = it >= n32
         B = int(rng.integers(1, 6)); T = int(rng.integers(1, 70)); U = int(rng.integers(0, 40))
         if bf:
-            H = int(rng.choice([128, 256, 384, 512])); V = int(rng.choice([128, 256, 384]))
+            H = int(rng.choice([128, 256, 384, 512])); V = 128 * int(rng.integers(1, max(2, maxv // 32) + 1))
         else:
-            H = 4 * int(rng.integers(1, 161)); V = 4 * int(rng.integers(1, 80))
+            H = 4 * int(rng.integers(1, maxh + 1)); V = 4 * int(rng.integers(1, maxv + 1))
         d = make_inputs(B, T, U, H, V, seed=int(rng.integers(1 << 30)))
         ll = rng.integers(1, T + 1, B); tl = rng.integers(0, U + 1, B)
         ll[rng.integers(B)] = T; tl[rng.integers(B)] = U
