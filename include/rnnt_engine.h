@@ -69,7 +69,9 @@ int rnnt_engine_debug_query(int what);
 /* Message of the last error on the calling thread ("" if none). */
 const char *rnnt_engine_last_error(void);
 
-/* Bytes of device workspace rnnt_engine_joint_loss_fwd_bwd needs for these dims. */
+/* Bytes of device workspace rnnt_engine_joint_loss_fwd_bwd needs for these dims.  The workspace is
+ * scratch: it need not be initialised (any bit pattern, NaNs included, is fine) and carries no
+ * state from one call to the next. */
 int rnnt_engine_workspace_bytes(int B, int T, int U1, int H, int V, int dtype, size_t *out);
 
 /* Bytes of device workspace rnnt_engine_loss_fwd_bwd needs for these dims. */
