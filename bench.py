@@ -32,6 +32,10 @@ CONFIGS = {
     "cfg4": (8, 4000, 600, 640, 1024),
     "cfg5": (16, 800, 150, 512, 16384),
     "small": (8, 200, 50, 512, 1024),
+    # the reference's real joint width (hidden_features: 1024 in every rnnt/config/*.yaml):
+    # BASELINE config 1's plumbing shape and a training-sized batch of it
+    "cfg1": (2, 208, 50, 1024, 1024),
+    "ref1024": (8, 500, 100, 1024, 1024),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
@@ -76,12 +80,15 @@ def cpu_baseline(T, U, H, V, budget_s=40.0):
     one(1, max(8, T // 50))  # warm-up (thread pools, allocator)
     t_probe = one(1, max(8, T // 10))
     est_full = t_probe * 10.0  # one utterance at full T
-    # ~10-30 s of CPU work: the probe over-estimates (thread pools warm up), so aim at the top
-    B = int(max(1, min(8, round(budget_s / max(est_full, 1e-3)))))
-    dt = one(B, T)
+    # BASELINE.md §3 protocol: 1 warm-up, median of 3 runs; the three together are the ~10-30 s of
+    # CPU work (the probe over-estimates: thread pools warm up), so each run gets a third
+    B = int(max(1, min(8, round(budget_s / 3.0 / max(est_full, 1e-3)))))
+    runs = sorted(one(B, T) for _ in range(3))
+    dt = runs[1]
     return {"value": B * T * U / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, 1 run of joint(torch CPU)+loss(C oracle) "
-                      f"fwd+bwd in {dt:.2f}s", "os_cpu_count": os.cpu_count()}
+            "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, median of 3 runs ({runs[0]:.2f}/{runs[1]:.2f}/{runs[2]:.2f} s) "
+                      f"of joint (torch CPU, {threads} threads) + loss (C oracle, OpenMP over the {B} utterances) fwd+bwd",
+            "runs_s": runs, "os_cpu_count": os.cpu_count()}
 
 
 def parity_twin(H, V, device, dtype="fp32"):
@@ -104,6 +111,46 @@ def parity_twin(H, V, device, dtype="fp32"):
                     (" with bf16 rounding points" if dtype == "bf16" else "")}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N rank
+    processes here, one per GPU — the process layout of reference rnnt/train.py:25-33 (mp.spawn,
+    one rank per device, "nccl").  The parent never touches the GPU (device_count() does not
+    initialise HIP); it refuses to run fewer ranks than asked for."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    single = os.environ.get("BENCH_SINGLE_DEVICE") == "1"  # rehearsal: every rank on cuda:0
+    if have < n and not (single and have >= 1):
+        print(json.dumps({"error": f"--gpus {n} requested but hipGetDeviceCount() = {have}; refusing to "
+                                   "benchmark fewer GPUs than asked for", "hipGetDeviceCount": have,
+                          "n_gpus_requested": n}), flush=True)
+        raise SystemExit(3)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:  # a rank that dies would leave the others waiting in a collective: stop them
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,10 +165,12 @@ def main():
                     help="skip the down-scaled parity twin (keeps rocprof kernel averages clean)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     # rehearsal knobs (not used by the driver): BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and
@@ -226,6 +275,9 @@ def main():
                    "global_batch": B, "per_gpu_batch": Bl, "parallelism": f"dp{world}",
                    "cells_BTU1": B * T * (U + 1)},
         "loss": loss,
+        # what actually ran: devices the runtime sees, ranks in the RCCL communicator
+        "hipGetDeviceCount": torch.cuda.device_count(),
+        "rccl_ranks": dist.get_world_size() if dist_on else 0,
     }
     flops_cell = 6.0 * H * V  # 2HV fwd + 2HV dHidden + 2HV dW per lattice cell
     cells1 = Bl * T * (U + 1)  # cells the GEMMs actually process per launch (U+1 columns)

@@ -19,7 +19,12 @@
  *   - return value 0 = success, negative = error (RNNT_ERR_*); the message is available
  *     from rnnt_engine_last_error() (thread-local);
  *   - lattice layout: logits [B,T,U1,V] row-major contiguous, U1 = max target length + 1;
- *     targets [B,U1-1] int32, blank never appears in targets; lengths int32 [B].
+ *     targets [B,U1-1] int32, blank never appears in targets; lengths int32 [B];
+ *   - precondition on the lengths (torchaudio checks the same on the host): 1 <= logit_lens[b] <= T,
+ *     0 <= target_lens[b] <= U1-1.  The kernels CLAMP what they read into those ranges, so a
+ *     violated precondition gives the loss of the clamped lattice, never an out-of-bounds access;
+ *   - the library keeps no mutable state besides the thread-local error string; the device the
+ *     pointers live on must be the calling thread's current HIP device.
  */
 #ifndef RNNT_ENGINE_H
 #define RNNT_ENGINE_H
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RNNT_ENGINE_VERSION 1
+#define RNNT_ENGINE_VERSION 2
 
 #define RNNT_DTYPE_F32 0 /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out */
 /* BASELINE config 3 ("bf16"): pointers stay fp32 at this boundary (inputs, parameters, costs,
@@ -52,16 +57,19 @@ extern "C" {
 /* Library version (RNNT_ENGINE_VERSION it was built with). */
 int rnnt_engine_version(void);
 
-/* Experiment switches read by the ablation code of diagnostic builds (-DRNNT_ABLATE; the shipped
- * kernels ignore them), bit 5 (32): force the separate k_make_g pass, and bit 6 (64): force the
- * separate k_make_hidden pass (the forward kernel otherwise fills hidden itself), bit 7 (128): forward
- * main loop with the LDS-DMA ring for W instead of register-streamed fragments, bit 8 (256): forward
- * launched as one workgroup per tile instead of persistent workgroups.  Returns the old value. */
+/* Diagnostic builds only (make EXTRA=-DRNNT_ABLATE / -DRNNT_STAMPS): process-wide ablation switches
+ * of tools/exp_*.py and the device buffer of the in-kernel time stamps.  In the shipped library
+ * both are no-ops (set_flags returns 0) — it has no global mutable state; alternative kernel
+ * variants are chosen per call through rnnt_engine_run_stages. */
 int rnnt_engine_set_flags(int flags);
-
-/* Device buffer for diagnostic in-kernel time stamps; only read by builds made with
- * -DRNNT_STAMPS (never the shipped one). NULL disables. */
 void rnnt_engine_set_debug(void *buf);
+
+/* Kernel variants a caller may ask for per call (rnnt_engine_run_stages).  Every variant multiplies
+ * the same numbers in the same order as the default kernels: results are bit-identical. */
+#define RNNT_VARIANT_SEPARATE_G 32          /* G by its own pass (k_make_g) + the persistent dHidden kernel */
+#define RNNT_VARIANT_SEPARATE_HIDDEN 64     /* hidden by its own pass instead of the forward prologue       */
+#define RNNT_VARIANT_FWD_LDS_RING 128       /* forward main loop: W through an LDS-DMA ring                 */
+#define RNNT_VARIANT_FWD_ONE_WG_PER_TILE 256 /* forward: one workgroup per tile instead of persistent ones   */
 
 /* Diagnostic queries (0/1: predicted resident forward-kernel workgroups per CU). */
 int rnnt_engine_debug_query(int what);
@@ -129,6 +137,31 @@ int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3]
                                    void *stream);
 
 /*
+ * Forward only: the per-utterance costs of the fused path and nothing else (no coefficient, dHidden
+ * or dW kernels, no gradient buffers).  What `RNNTModel.forward` costs under torch.no_grad() —
+ * the validation loss of reference rnnt/train.py:170-201 / rnnt/model.py:32-41.  Same workspace size
+ * as rnnt_engine_joint_loss_fwd_bwd.
+ */
+int rnnt_engine_joint_loss_fwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                               const void *W, const void *bias, const int32_t *targets,
+                               const int32_t *logit_lens, const int32_t *target_lens, int B, int T,
+                               int U1, int H, int V, int blank, int dtype, float *costs,
+                               void *workspace, size_t ws_bytes, void *stream);
+
+/*
+ * Backward of the UNFUSED joint: given d loss / d logits (any upstream gradient, [B,T,U1,V]
+ * contiguous fp32) returns the gradients autograd sends through reference rnnt/joint.py:32-39
+ * (joint_ln, tanh, the broadcast add): grad_enc [B,T,H], grad_pred [B,U1,H], grad_W [V,H],
+ * grad_bias [V].  Serves callers that keep `joint(...)` and the loss as two calls (a maintainer
+ * who swaps only rnnt/joint.py); fp32 only.
+ */
+int rnnt_engine_joint_bwd_workspace_bytes(int B, int T, int U1, int H, int V, int dtype, size_t *out);
+int rnnt_engine_joint_bwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                          const void *W, const void *grad_logits, int B, int T, int U1, int H, int V,
+                          int dtype, void *grad_enc, void *grad_pred, void *grad_W, void *grad_bias,
+                          void *workspace, size_t ws_bytes, void *stream);
+
+/*
  * Greedy-decode scan (next-step row SURVEY.md 8f-2).  The reference's decode loop, rnnt/model.py:108-125,
  * evaluates joint.single_forward (rnnt/joint.py:44-55) for one audio frame at a time and syncs on
  * argmax(...).item() per frame.  This call evaluates frames t0 .. t0+nframes-1 (nframes <= 128) of
@@ -174,6 +207,18 @@ int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[
                           int blank, float clamp, float grad_scale, int dtype, float *costs,
                           void *grad_enc, void *grad_pred, void *grad_W, void *grad_bias,
                           void *workspace, size_t ws_bytes, void *stream);
+
+/*
+ * Any subset of the stages (bit s of `stage_mask` = stage s above; 255 = the whole pipeline) with
+ * the kernel variants of `variant` (RNNT_VARIANT_*), chosen for this call only.  Gradient
+ * pointers may be NULL when no backward stage (4..7) is selected.  Test / bench aid.
+ */
+int rnnt_engine_run_stages(int stage_mask, int variant, const void *enc, const int64_t enc_strides[3],
+                           const void *pred, const void *W, const void *bias, const int32_t *targets,
+                           const int32_t *logit_lens, const int32_t *target_lens, int B, int T, int U1,
+                           int H, int V, int blank, float clamp, float grad_scale, int dtype,
+                           float *costs, void *grad_enc, void *grad_pred, void *grad_W,
+                           void *grad_bias, void *workspace, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         if (c_first >= cells) return;
         const long b_first = c_first / per;
         if (c_last < cells && c_last / per == b_first &&
-            (c_first - b_first * per) / a.U1 >= a.logit_lens[b_first]) return;
+            (c_first - b_first * per) / a.U1 >= len_t(a.logit_lens, b_first, a.T)) return;
     }
     const long row0 = (long)blockIdx.x * 128 + wave * 32;
     const u32x4 *ap = (const u32x4 *)(a.hidden + (row0 + j) * H) + 2 * half;  // chunk c: ap[4c], ap[4c+1]
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         const int u = (int)(cell % U1);
         const long bt = cell / U1;
         const int t = (int)(bt % T), b = (int)(bt / T);
-        const int Ub = a.target_lens[b];
-        if (t < a.logit_lens[b] && u <= Ub) {
+        const int Ub = len_u(a.target_lens, b, a.U1);
+        if (t < len_t(a.logit_lens, b, a.T) && u <= Ub) {
             const float den = s_den[wave * 32 + j];
             const unsigned short *lrow = a.logits + cell * V;
             const long si = skew_index(b, t, u, a.D, U1);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     const int j = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
-    const int Tb = a.logit_lens[b];
+    const int Tb = len_t(a.logit_lens, b, a.T);
     const int t0 = tt * BG_BT, u0 = ub * BG_BU;
     const int VC = V / 32;
 
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
 
     // workgroup-uniform: no products past the utterance's length or in a u block past U_b (no
     // lattice cell; the reductions skip its slabs), but k_dw_bf16 must find zeros in these rows
-    if (t0 >= Tb || u0 > a.target_lens[b]) {
+    if (t0 >= Tb || u0 > len_u(a.target_lens, b, a.U1)) {
         if (pexists) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int c = 0; c < VC; ++c) grow[4 * c] = z;

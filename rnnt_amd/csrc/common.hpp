@@ -24,6 +24,21 @@ __device__ __forceinline__ long skew_index(int b, int t, int u, int D, int U1)
     return ((long)b * D + (t + u)) * U1 + u;
 }
 
+// Utterance lengths as every kernel reads them: clamped into the lattice (1 <= T_b <= T,
+// 0 <= U_b <= U1-1), so a bad length from a caller that skipped the host-side checks
+// (check_lengths=False, or the C ABI called directly) can never index outside the per-utterance
+// arrays or the LDS mailboxes; it yields the loss of the clamped lattice instead of a fault.
+__device__ __forceinline__ int len_t(const int32_t *logit_lens, int b, int T)
+{
+    const int v = logit_lens[b];
+    return v < 1 ? 1 : (v > T ? T : v);
+}
+__device__ __forceinline__ int len_u(const int32_t *target_lens, int b, int U1)
+{
+    const int v = target_lens[b];
+    return v < 0 ? 0 : (v > U1 - 1 ? U1 - 1 : v);
+}
+
 // tanh via one v_exp_f32 + one v_rcp_f32: 1 - 2/(exp(2x)+1).  Saturates correctly at
 // +-inf; absolute error <~3e-7 (the result feeds a dot product, absolute error matters).
 __device__ __forceinline__ float fast_tanh(float x)

@@ -14,8 +14,17 @@
 namespace {
 
 thread_local std::string g_err;
-int g_flags = 0;  // experiment switches (rnnt_engine_set_flags)
-unsigned long long *g_debug = nullptr;  // diagnostic stamp buffer (rnnt_engine_set_debug)
+// The shipped library keeps NO mutable state besides the thread-local error string: kernel
+// variants are selected per call (rnnt_engine_run_stages).  Only diagnostic builds
+// (-DRNNT_ABLATE: in-kernel ablation switches; -DRNNT_STAMPS: s_memtime stamps) carry the
+// process-wide words rnnt_engine_set_flags / rnnt_engine_set_debug write.
+#if defined(RNNT_ABLATE) || defined(RNNT_STAMPS)
+int g_flags = 0;
+unsigned long long *g_debug = nullptr;
+#else
+constexpr int g_flags = 0;
+constexpr unsigned long long *g_debug = nullptr;
+#endif
 
 int fail(int code, const char *fmt, ...)
 {
@@ -121,23 +130,25 @@ void resolve_enc(const void *enc, const int64_t s[3], int B, int T, int H, float
     }
 }
 
+// compute units of the CURRENT device (the caller makes the tensors' device current); read-only
+// facts of the hardware, cached per device id
 int device_cus()
 {
-    static thread_local int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    static thread_local int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!cus[dev]) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus[dev] = p.multiProcessorCount;
+        if (cus[dev] <= 0) cus[dev] = 256;
     }
-    return cus;
+    return cus[dev];
 }
 
 enum { ST_PROD = 1, ST_FWD = 2, ST_LATTICE = 4, ST_COEF = 8, ST_DH = 16, ST_DH_RED = 32, ST_DW = 64,
        ST_DW_RED = 128, ST_ALL = 255 };
 
-int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const void *pred,
+int run_fused(int stages, int variant, const void *enc, const int64_t enc_strides[3], const void *pred,
               const void *W, const void *bias, const int32_t *targets, const int32_t *logit_lens,
               const int32_t *target_lens, int B, int T, int U1, int H, int V, int blank,
               float clamp, float grad_scale, int dtype, float *costs, void *grad_enc,
@@ -146,8 +157,11 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
 {
     if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
     if (!enc || !enc_strides || !pred || !W || !bias || !targets || !logit_lens || !target_lens ||
-        !costs || !grad_enc || !grad_pred || !grad_W || !grad_bias || !workspace)
+        !costs || !workspace)
         return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    const bool backward = (stages & (ST_DH | ST_DH_RED | ST_DW | ST_DW_RED)) != 0;
+    if (backward && (!grad_enc || !grad_pred || !grad_W || !grad_bias))
+        return fail(RNNT_ERR_INVALID_ARG, "null gradient pointer");
     if (blank < 0 || blank >= V) return fail(RNNT_ERR_INVALID_ARG, "blank=%d outside [0,%d)", blank, V);
     if (clamp > 0.f) return fail(RNNT_ERR_UNSUPPORTED, "clamp>0 is only supported by rnnt_engine_loss_fwd_bwd");
     if (!(grad_scale > 0.f)) return fail(RNNT_ERR_INVALID_ARG, "grad_scale must be > 0");
@@ -155,6 +169,8 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         !aligned16(grad_pred) || !aligned16(grad_W) || !aligned16(grad_bias) ||
         ((uintptr_t)workspace & 255))
         return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
+    const int xflags = g_flags | (variant & (RNNT_VARIANT_SEPARATE_G | RNNT_VARIANT_SEPARATE_HIDDEN |
+                                             RNNT_VARIANT_FWD_LDS_RING | RNNT_VARIANT_FWD_ONE_WG_PER_TILE));
     rnnt_engine_ws_layout L;
     layout(B, T, U1, H, V, dtype, &L);
     if (ws_bytes < L.total)
@@ -182,7 +198,7 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
-    g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = g_flags & ~16; g.debug = g_debug;
+    g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = xflags & ~16; g.debug = g_debug;
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;
         h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;
@@ -195,13 +211,14 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         h.slab_enc = g.slab_enc; h.slab_pred = g.slab_pred; h.slab_w = g.slab_w; h.slab_b = g.slab_b;
         h.rows_pad = (long)L.rows_pad; h.rows_alloc = bf16_rows_alloc(L.rows_pad);
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
-        h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = g_flags;
+        h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags;
         h.dw_tab = (long *)(ws + L.counters + 1024);
         g.flags |= 16;  // reductions: dPred slabs are 8 t-rows high, as in k_dhidden_gen
         if (stages & ST_PROD) launch_bf16_producers(h, st);
         if (stages & ST_FWD) launch_joint_fwd_bf16(h, st);  // softmax statistics in its epilogue
         if (stages & ST_LATTICE)
-            launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D, st);
+            launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D,
+                           (unsigned *)(ws + L.counters + 768), st);
         if (stages & ST_COEF)
             launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                         B, T, U1, L.D, grad_scale, st);
@@ -212,12 +229,12 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
         return launch_status("rnnt_engine fused pipeline (bf16)");
     }
     // G inside the dHidden GEMM unless the shape needs the separate pass (or flag 32 forces it)
-    const bool fuse_g = dhidden_gen_ok(H, V) && !(g_flags & 32);
+    const bool fuse_g = dhidden_gen_ok(H, V, U1) && !(xflags & 32);
     if (fuse_g) g.flags |= 16;
 
     // hidden (A operand of all three GEMMs) is produced by the forward kernel for its own tile
     // unless flag 64 asks for the separate k_make_hidden pass
-    const bool fuse_hid = !(g_flags & 64) && !(g_flags & 8);
+    const bool fuse_hid = !(xflags & 64) && !(xflags & 8);
     if (stages & ST_PROD) {
         if (fuse_hid) {  // only the zero padding rows the dW GEMM walks past the last cell
             const size_t cells = (size_t)B * T * U1;
@@ -230,16 +247,17 @@ int run_fused(int stages, const void *enc, const int64_t enc_strides[3], const v
     if (stages & ST_FWD) {
         JointFwdArgs f;
         f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred;
-        f.wpack = wpack; f.hidden = (g_flags & 8) ? nullptr : g.hidden; f.bias = (const float *)bias; f.targets = targets;
+        f.wpack = wpack; f.hidden = (xflags & 8) ? nullptr : g.hidden; f.bias = (const float *)bias; f.targets = targets;
         f.logit_lens = logit_lens; f.target_lens = target_lens; f.logits = logits;
         f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
-        f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = g_flags; f.debug = g_debug;
+        f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = xflags; f.debug = g_debug;
         f.make_hidden = fuse_hid ? 1 : 0;
         f.counter = (unsigned *)(ws + L.counters + 512); f.n_cu = device_cus();
         launch_joint_fwd(f, st);
     }
     if (stages & ST_LATTICE)
-        launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D, st);
+        launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D,
+                           (unsigned *)(ws + L.counters + 768), st);
     if (stages & ST_COEF)
         launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                     B, T, U1, L.D, grad_scale, st);
@@ -259,9 +277,13 @@ extern "C" {
 
 int rnnt_engine_version(void) { return RNNT_ENGINE_VERSION; }
 
+#if defined(RNNT_ABLATE) || defined(RNNT_STAMPS)
 int rnnt_engine_set_flags(int flags) { int o = g_flags; g_flags = flags; return o; }
-
 void rnnt_engine_set_debug(void *buf) { g_debug = (unsigned long long *)buf; }
+#else  // shipped build: no process-wide state; the symbols stay so diagnostic tools link
+int rnnt_engine_set_flags(int) { return 0; }
+void rnnt_engine_set_debug(void *) {}
+#endif
 
 int rnnt_engine_debug_query(int what) { return fwd_occupancy(what); }
 
@@ -290,7 +312,7 @@ int rnnt_engine_loss_workspace_bytes(int B, int T, int U1, int V, int dtype, siz
     if (!out) return fail(RNNT_ERR_INVALID_ARG, "null size pointer");
     if (int rc = check_dims(B, T, U1, 4, V, dtype, false)) return rc;
     const size_t D = (size_t)T + U1 - 1, skew = (size_t)B * D * U1, cells = (size_t)B * T * U1;
-    *out = 3 * align_up(skew * 4) + 2 * align_up(skew * 8) + align_up(cells * 16);
+    *out = 3 * align_up(skew * 4) + 2 * align_up(skew * 8) + align_up(cells * 16) + 256;  // + error word
     return RNNT_OK;
 }
 
@@ -330,6 +352,63 @@ int rnnt_engine_joint_fwd(const void *enc, const int64_t enc_strides[3], const v
     f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = T + U1 - 1; f.blank = V - 1; f.flags = g_flags; f.debug = g_debug;
     launch_joint_fwd(f, st);
     return launch_status("rnnt_engine_joint_fwd");
+}
+
+int rnnt_engine_joint_bwd_workspace_bytes(int B, int T, int U1, int H, int V, int dtype, size_t *out)
+{
+    if (dtype != RNNT_DTYPE_F32) return fail(RNNT_ERR_UNSUPPORTED, "rnnt_engine_joint_bwd is fp32 only");
+    return rnnt_engine_workspace_bytes(B, T, U1, H, V, dtype, out);
+}
+
+int rnnt_engine_joint_bwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                          const void *W, const void *grad_logits, int B, int T, int U1, int H, int V,
+                          int dtype, void *grad_enc, void *grad_pred, void *grad_W, void *grad_bias,
+                          void *workspace, size_t ws_bytes, void *stream)
+{
+    if (dtype != RNNT_DTYPE_F32) return fail(RNNT_ERR_UNSUPPORTED, "rnnt_engine_joint_bwd is fp32 only");
+    if (int rc = check_dims(B, T, U1, H, V, dtype, true)) return rc;
+    if (!enc || !enc_strides || !pred || !W || !grad_logits || !grad_enc || !grad_pred || !grad_W ||
+        !grad_bias || !workspace)
+        return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    if (!aligned16(pred) || !aligned16(W) || !aligned16(grad_logits) || !aligned16(grad_enc) ||
+        !aligned16(grad_pred) || !aligned16(grad_W) || !aligned16(grad_bias) || ((uintptr_t)workspace & 255))
+        return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
+    rnnt_engine_ws_layout L;
+    layout(B, T, U1, H, V, dtype, &L);
+    if (ws_bytes < L.total) return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    const float *encp; long esb, est;
+    resolve_enc(enc, enc_strides, B, T, H, (float *)(ws + L.enc_copy), st, &encp, &esb, &est);
+    // every utterance at full length: the upstream gradient is dense (zero where the caller's loss
+    // ignored a cell); the length arrays the kernels read live in the (unused) coefficient region
+    int32_t *ll = (int32_t *)(ws + L.coef), *tl = ll + B;
+    (void)hipMemsetD32Async((hipDeviceptr_t)ll, T, B, st);
+    (void)hipMemsetD32Async((hipDeviceptr_t)tl, U1 - 1, B, st);
+    // G with the zero padding rows the dW GEMM walks past the last cell
+    const size_t cells = (size_t)B * T * U1;
+    float *G = (float *)(ws + L.logits);
+    (void)hipMemcpyAsync(G, grad_logits, cells * V * 4, hipMemcpyDeviceToDevice, st);
+    (void)hipMemsetAsync(G + cells * V, 0, (L.rows_pad + 16 - cells) * V * 4, st);
+    JointBwdArgs g;
+    memset(&g, 0, sizeof g);
+    g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred; g.W = (const float *)W;
+    g.logits = G; g.hidden = (float *)(ws + L.hidden); g.rows_pad = (long)L.rows_pad;
+    g.logit_lens = ll; g.target_lens = tl;
+    g.slab_enc = (float *)(ws + L.slab_enc); g.slab_pred = (float *)(ws + L.slab_pred);
+    g.slab_w = (float *)(ws + L.slab_w); g.slab_b = (float *)(ws + L.slab_b);
+    g.grad_enc = (float *)grad_enc; g.grad_pred = (float *)grad_pred;
+    g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
+    g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = V - 1;
+    g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
+    g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024);
+    g.n_cu = device_cus(); g.flags = 0; g.debug = nullptr;
+    launch_make_hidden(g, st);
+    launch_dhidden(g, st);
+    launch_dhidden_reduce(g, st);
+    launch_dw(g, st);
+    launch_dw_reduce(g, st);
+    return launch_status("rnnt_engine_joint_bwd");
 }
 
 int rnnt_engine_greedy_scan_workspace_bytes(int nframes, int H, int V, size_t *out)
@@ -388,11 +467,12 @@ int rnnt_engine_loss_fwd_bwd(const void *logits, const int32_t *targets, const i
     float *lpe_s = (float *)ws;   ws += align_up(skew * 4);
     double *alpha_s = (double *)ws; ws += align_up(skew * 8);
     double *beta_s = (double *)ws;  ws += align_up(skew * 8);
-    CellCoef *coef = (CellCoef *)ws;
+    CellCoef *coef = (CellCoef *)ws; ws += align_up((size_t)B * T * U1 * 16);
+    unsigned *err = (unsigned *)ws;
     hipStream_t st = (hipStream_t)stream;
     launch_logsoftmax_gather((const float *)logits, targets, logit_lens, target_lens, denom_s, lpb_s,
                              lpe_s, B, T, U1, V, D, blank, st);
-    launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, D, st);
+    launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, D, err, st);
     if (grad_logits) {
         launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                     B, T, U1, D, 1.0f, st);
@@ -410,8 +490,32 @@ int rnnt_engine_joint_loss_fwd_bwd(const void *enc, const int64_t enc_strides[3]
                                    void *grad_pred, void *grad_W, void *grad_bias, void *workspace,
                                    size_t ws_bytes, void *stream)
 {
-    return run_fused(ST_ALL, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens, B, T,
+    return run_fused(ST_ALL, 0, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens, B, T,
                      U1, H, V, blank, clamp, grad_scale, dtype, costs, grad_enc, grad_pred, grad_W,
+                     grad_bias, workspace, ws_bytes, stream);
+}
+
+int rnnt_engine_joint_loss_fwd(const void *enc, const int64_t enc_strides[3], const void *pred,
+                               const void *W, const void *bias, const int32_t *targets,
+                               const int32_t *logit_lens, const int32_t *target_lens, int B, int T,
+                               int U1, int H, int V, int blank, int dtype, float *costs,
+                               void *workspace, size_t ws_bytes, void *stream)
+{
+    return run_fused(ST_PROD | ST_FWD | ST_LATTICE, 0, enc, enc_strides, pred, W, bias, targets, logit_lens,
+                     target_lens, B, T, U1, H, V, blank, -1.0f, 1.0f, dtype, costs, nullptr, nullptr,
+                     nullptr, nullptr, workspace, ws_bytes, stream);
+}
+
+int rnnt_engine_run_stages(int stage_mask, int variant, const void *enc, const int64_t enc_strides[3],
+                           const void *pred, const void *W, const void *bias, const int32_t *targets,
+                           const int32_t *logit_lens, const int32_t *target_lens, int B, int T, int U1,
+                           int H, int V, int blank, float clamp, float grad_scale, int dtype,
+                           float *costs, void *grad_enc, void *grad_pred, void *grad_W,
+                           void *grad_bias, void *workspace, size_t ws_bytes, void *stream)
+{
+    if (stage_mask <= 0 || stage_mask > ST_ALL) return fail(RNNT_ERR_INVALID_ARG, "stage_mask %d outside [1,255]", stage_mask);
+    return run_fused(stage_mask, variant, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens,
+                     B, T, U1, H, V, blank, clamp, grad_scale, dtype, costs, grad_enc, grad_pred, grad_W,
                      grad_bias, workspace, ws_bytes, stream);
 }
 
@@ -424,7 +528,7 @@ int rnnt_engine_run_stage(int stage, const void *enc, const int64_t enc_strides[
                           size_t ws_bytes, void *stream)
 {
     if (stage < 0 || stage > 7) return fail(RNNT_ERR_INVALID_ARG, "stage %d outside [0,7]", stage);
-    return run_fused(1 << stage, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens,
+    return run_fused(1 << stage, 0, enc, enc_strides, pred, W, bias, targets, logit_lens, target_lens,
                      B, T, U1, H, V, blank, clamp, grad_scale, dtype, costs, grad_enc, grad_pred,
                      grad_W, grad_bias, workspace, ws_bytes, stream);
 }

@@ -54,12 +54,14 @@ struct PwChunk {
     f32x4 w[4];  // W rows k0+4*half+s, columns n0+4j..4j+3
 };
 
-__global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
+// `cb0`: first 128-column block this launch covers (0, or 4 when k_dhidden_gen has produced G and
+// the first 512 columns: H > 512).
+__global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a, int cb0)
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
-    const int n_cb = (H + 127) / 128, n_ub = (U1 + DH_BU - 1) / DH_BU, n_tt = (T + PW_BT - 1) / PW_BT;
+    const int n_cb = (H + 127) / 128 - cb0, n_ub = (U1 + DH_BU - 1) / DH_BU, n_tt = (T + PW_BT - 1) / PW_BT;
     const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0
     // V % 8 == 4: in the last chunk lanes 32-63 would start at k >= V; they step back 4
     // (valid addresses) and their G values are zeroed
@@ -84,14 +86,17 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a)
         if (lane == 0) item = (long)atomicAdd(a.counter + q * 16, 1u);
         item = __builtin_amdgcn_readfirstlane((int)item);
         if (item >= q_items) break;
-        const int cb = (int)(item % n_cb);
+        const int cb = cb0 + (int)(item % n_cb);
         long r_ = (item / n_cb) * 8 + q;  // tile id
         const int ub = (int)(r_ % n_ub); r_ /= n_ub;
         const int tt = (int)(r_ % n_tt);
         const int b = (int)(r_ / n_tt);
-        const int Tb = a.logit_lens[b];
+        const int Tb = len_t(a.logit_lens, b, a.T);
         const int t0 = tt * PW_BT, u0 = ub * DH_BU;
         if (t0 >= Tb) continue;  // wave-uniform
+        // a u block past U_b holds no lattice cell (G == 0 there): its slabs are never read
+        // (k_reduce_enc / k_reduce_pred stop at U_b)
+        if (u0 > len_u(a.target_lens, b, a.U1)) continue;
         const int col = cb * 128 + 4 * i;
         const bool colok = col < H;
 
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
-    const int Tb = a.logit_lens[b];
+    const int Tb = len_t(a.logit_lens, b, a.T);
     const int t0 = tt * DG_BT, u0 = ub * DH_BU;
     const int VK = V / 8;
 
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         }
         return;
     }
-    if (u0 > a.target_lens[b]) {  // workgroup-uniform: a u block past U_b holds no lattice cell — its G
+    if (u0 > len_u(a.target_lens, b, a.U1)) {  // workgroup-uniform: a u block past U_b holds no lattice cell — its G
         if (pexists) {  // rows are zeros (k_dw walks them), its slabs are never read
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;
@@ -600,14 +605,23 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     GSTAMP(3);
 }
 
-bool dhidden_gen_ok(int H, int V) { return H <= 512 && (V % 32) == 0; }
+// k_dhidden_gen applies: V in whole 32-wide chunk quadruples, and its raw buffers (num_records is
+// 32-bit, per-lane offsets are 32-bit) can span W and one tile's logits / hidden rows.  It covers
+// the first 512 columns of H; launch_dhidden sends the rest to k_dhidden.
+bool dhidden_gen_ok(int H, int V, int U1)
+{
+    const long span_rows = (long)(DG_BT - 1) * U1 + DH_BU;
+    const long wide = V > H ? V : H;
+    return (V % 32) == 0 && (long)V * H * 4 < 0xffffffffL && span_rows * wide * 4 < 0x7fffffffL;
+}
+#define DG_COLS 512  // columns of H one k_dhidden_gen workgroup covers
 
 // out[b,t,:] = sum_ub slab_enc[ub][b,t,:]  (0 for t >= T_b)
 __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ slab,
                                                     const int32_t *__restrict__ logit_lens,
                                                     const int32_t *__restrict__ target_lens,
-                                                    float *__restrict__ out, int B, int T, int H,
-                                                    int n_ublk)
+                                                    float *__restrict__ out, int B, int T, int U1,
+                                                    int H, int n_ublk)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
     const int H4 = H / 4;
@@ -616,32 +630,34 @@ __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ sl
     const long bt = idx / H4;
     const int t = (int)(bt % T), b = (int)(bt / T);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (t < logit_lens[b]) {
+    if (t < len_t(logit_lens, b, T)) {
         // u blocks that start past U_b hold no lattice cell; the fused dHidden kernels skip them
         // without writing their slab
-        int nub = target_lens[b] / DH_BU + 1;
+        int nub = len_u(target_lens, b, U1) / DH_BU + 1;
         if (nub > n_ublk) nub = n_ublk;
         for (int k = 0; k < nub; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
     }
     ((f32x4 *)out)[idx] = s;
 }
 
-// out[b,u,:] = sum_{tt < ceil(T_b/8)} slab_pred[tt][b,u,:]
+// out[b,u,:] = sum_{tt < ceil(T_b/bt)} slab_pred[tt][b,u,:]; the t tiles are bt_lo rows high for
+// columns < col_split (k_dhidden_gen: 8) and bt_hi for the others (k_dhidden: 4)
 __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ slab,
                                                      const int32_t *__restrict__ logit_lens,
                                                      const int32_t *__restrict__ target_lens,
-                                                     float *__restrict__ out, int B, int U1, int H,
-                                                     int bt)
+                                                     float *__restrict__ out, int B, int T, int U1,
+                                                     int H, int bt_lo, int bt_hi, int col_split)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int H4 = H / 4;
     const long n = (long)B * U1 * H4;
     if (idx >= n) return;
     const int b = (int)(idx / ((long)U1 * H4));
-    const int ntt = (logit_lens[b] + bt - 1) / bt;  // slabs written: t tiles of height bt
+    const int bt = 4 * (int)(idx % H4) < col_split ? bt_lo : bt_hi;
+    const int ntt = (len_t(logit_lens, b, T) + bt - 1) / bt;  // slabs written: t tiles of height bt
     const int u = (int)((idx / H4) % U1);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (u <= target_lens[b])  // rows past U_b: no lattice cell, and their u block may not have been written
+    if (u <= len_u(target_lens, b, U1))  // rows past U_b: no lattice cell, and their u block may not have been written
         for (int k = 0; k < ntt; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
     ((f32x4 *)out)[idx] = s;
 }
@@ -654,21 +670,23 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
         (void)hipMemsetAsync((float *)a.logits + cells * a.V, 0, (size_t)(a.rows_pad + 16 - cells) * a.V * 4, st);
         dim3 grid(a.n_ublk, (a.T + DG_BT - 1) / DG_BT, a.B);
         hipLaunchKernelGGL(k_dhidden_gen, grid, dim3(256), 0, st, a);
-        return;
+        if (a.H <= DG_COLS) return;
+        // H > 512 (the reference's joint is 1024 wide): G now stands in place of the logits; the
+        // remaining column blocks are plain G x W products for the persistent kernel
     }
     (void)hipMemsetAsync(a.counter, 0, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
-    hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
 }
 
 void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)
 {
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,
-                       a.slab_enc, a.logit_lens, a.target_lens, a.grad_enc, a.B, a.T, a.H, a.n_ublk);
+                       a.slab_enc, a.logit_lens, a.target_lens, a.grad_enc, a.B, a.T, a.U1, a.H, a.n_ublk);
     const long n4p = (long)a.B * a.U1 * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_pred, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st,
-                       a.slab_pred, a.logit_lens, a.target_lens, a.grad_pred, a.B, a.U1, a.H,
-                       (a.flags & 16) ? DG_BT : PW_BT);
+                       a.slab_pred, a.logit_lens, a.target_lens, a.grad_pred, a.B, a.T, a.U1, a.H,
+                       (a.flags & 16) ? DG_BT : PW_BT, PW_BT, (a.flags & 16) ? DG_COLS : 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -776,7 +794,7 @@ __global__ void k_dw_table(const int32_t *__restrict__ logit_lens, int B, int T,
     long prev_end = 0, cum = 0;
     for (int b = 0; b < B; ++b) {
         const long c0 = (long)b * T * U1;
-        long s = c0 / gran, e = (c0 + (long)logit_lens[b] * U1 + gran - 1) / gran;
+        long s = c0 / gran, e = (c0 + (long)len_t(logit_lens, b, T) * U1 + gran - 1) / gran;
         if (s < prev_end) s = prev_end;
         if (e < s) e = s;
         tab[b] = s;

@@ -398,7 +398,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     const int b = by_;
     const int m0 = bx_ * FWD_ROWS;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
-    const int Tb = WITH_LOSS ? a.logit_lens[b] : T;
+    const int Tb = WITH_LOSS ? len_t(a.logit_lens, b, a.T) : T;
     const int ncell = Tb * U1;
     if (MAKE_HID) {
         // hidden = tanh(enc + pred) for this tile's cells, produced here instead of by a separate
@@ -479,7 +479,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                 ((unsigned long long)xcc << 32) | hw;
     }
 #endif
-    const int Ub = WITH_LOSS ? a.target_lens[b] : U1 - 1;
+    const int Ub = WITH_LOSS ? len_u(a.target_lens, b, a.U1) : U1 - 1;
 
     // per-lane running (max, sum-exp) of the 16 accumulator rows this lane sees, parked in LDS
     // between passes (slot [r][tid]: conflict-free) so it costs no VGPRs in the main loop;

@@ -9,7 +9,7 @@ void launch_logsoftmax_gather(const float *logits, const int32_t *targets,
                               int V, int D, int blank, hipStream_t st);
 void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, double *beta_s,
                     const int32_t *logit_lens, const int32_t *target_lens, float *costs, int B,
-                    int U1, int D, hipStream_t st);
+                    int U1, int D, unsigned *err /* one word of workspace */, hipStream_t st);
 void launch_coef(const double *alpha_s, const double *beta_s, const float *denom_s,
                  const float *lpb_s, const float *lpe_s, const int32_t *targets,
                  const int32_t *logit_lens, const int32_t *target_lens, CellCoef *coef, int B,
@@ -73,7 +73,7 @@ void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
 void launch_make_g(const JointBwdArgs &a, hipStream_t st);
-bool dhidden_gen_ok(int H, int V);  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
+bool dhidden_gen_ok(int H, int V, int U1);  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
 
 // ---- bf16.hip (RNNT_DTYPE_BF16 route: bf16 GEMM operands, fp32 accumulate / logits / loss)
 struct Bf16Args {

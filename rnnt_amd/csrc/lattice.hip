@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_logsoftmax_gather(
     const long bt = row / U1;
     const int t = (int)(bt % T);
     const int b = (int)(bt / T);
-    if (t >= logit_lens[b] || u > target_lens[b]) return;
+    if (t >= len_t(logit_lens, b, T) || u > len_u(target_lens, b, U1)) return;
     const float *x = logits + row * V;
     float m = RNNT_NEG_INF;
     for (int v = lane * 4; v < V; v += 256) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_logsoftmax_gather(
         const long si = skew_index(b, t, u, D, U1);
         denom_s[si] = den;
         lpb_s[si] = x[blank] - den;
-        lpe_s[si] = (u < target_lens[b]) ? x[targets[(long)b * (U1 - 1) + u]] - den : 0.f;
+        lpe_s[si] = (u < len_u(target_lens, b, U1)) ? x[targets[(long)b * (U1 - 1) + u]] - den : 0.f;
     }
 }
 
@@ -88,8 +88,9 @@ __device__ __forceinline__ void lattice_sweep(
     const int NT = blockDim.x;
     const int b = blockIdx.x;
     const int u = threadIdx.x;
-    const int Tb = logit_lens[b];
-    const int Ub = target_lens[b];
+    const int T = D - U1 + 1;
+    const int Tb = len_t(logit_lens, b, T);
+    const int Ub = len_u(target_lens, b, U1);
     const int nd = Tb + Ub;  // valid anti-diagonals 0 .. nd-1
     double *buf[2] = {sm, sm + NT + 2};
     const double NINF = (double)RNNT_NEG_INF;
@@ -204,7 +205,7 @@ template <int DIR>
 __device__ __forceinline__ void lattice_chain(
     const float *__restrict__ lpb_s, const float *__restrict__ lpe_s, double *__restrict__ out_s,
     const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
-    float *__restrict__ costs, int U1, int D)
+    float *__restrict__ costs, int U1, int D, unsigned *__restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int NW = blockDim.x >> 6;
@@ -219,7 +220,8 @@ __device__ __forceinline__ void lattice_chain(
     __syncthreads();  // the only barrier of the sweep
 
     const int b = blockIdx.x;
-    const int Tb = logit_lens[b], Ub = target_lens[b];
+    const int T = D - U1 + 1;
+    const int Tb = len_t(logit_lens, b, T), Ub = len_u(target_lens, b, U1);
     const int nd = Tb + Ub;  // valid anti-diagonals 0 .. nd-1
     const long base = (long)b * D * U1;
     const float *lpb = lpb_s + base, *lpe = lpe_s + base;
@@ -275,6 +277,10 @@ __device__ __forceinline__ void lattice_chain(
         const int d = DIR == 0 ? k : nd - 1 - k;
         if (has_cons && tg != k) {  // wave-uniform; rare once the waves have settled a step apart
             for (int spin = 0; tg != k && spin < (1 << 22); ++spin) { tg = mtag[cb + k - 1]; bv = mval[cb + k - 1]; }
+            // bounded spin exhausted (the producer wave never published step k-1: cannot happen
+            // while the workgroup is resident, but a silent stale value would be a wrong loss):
+            // raise the error word; k_lattice_status then turns every cost of the call into NaN
+            if (tg != k && l == 0) atomicOr(err, 1u);
         }
         // neighbour column of the previous diagonal: u-1 (alpha) / u+1 (beta); the lane at the
         // wave's edge keeps the mailbox value (-inf at the lattice's edge)
@@ -324,12 +330,21 @@ __global__ __launch_bounds__(1024) void k_lattice_chain(
     const float *__restrict__ lpb_s, const float *__restrict__ lpe_s,
     double *__restrict__ alpha_s, double *__restrict__ beta_s,
     const int32_t *__restrict__ logit_lens, const int32_t *__restrict__ target_lens,
-    float *__restrict__ costs, int U1, int D)
+    float *__restrict__ costs, int U1, int D, unsigned *__restrict__ err)
 {
     if (blockIdx.y == 0)
-        lattice_chain<0>(lpb_s, lpe_s, alpha_s, logit_lens, target_lens, costs, U1, D);
+        lattice_chain<0>(lpb_s, lpe_s, alpha_s, logit_lens, target_lens, costs, U1, D, err);
     else
-        lattice_chain<1>(lpb_s, lpe_s, beta_s, logit_lens, target_lens, costs, U1, D);
+        lattice_chain<1>(lpb_s, lpe_s, beta_s, logit_lens, target_lens, costs, U1, D, err);
+}
+
+// Failure report of the chained sweep: if any wave ran out of its bounded spin, the costs of the
+// whole call become NaN (a loud failure the training loop sees in its loss) instead of numbers
+// computed from a stale mailbox value.
+__global__ void k_lattice_status(const unsigned *__restrict__ err, float *__restrict__ costs, int B)
+{
+    if (*err == 0u) return;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) costs[b] = __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(256) void k_coef(
     const int u = (int)(rem - (long)d * U1);
     const int t = d - u;
     if (t < 0 || t >= T) return;
-    const int Tb = logit_lens[b], Ub = target_lens[b];
+    const int Tb = len_t(logit_lens, b, T), Ub = len_u(target_lens, b, U1);
     CellCoef c;
     c.c1 = RNNT_NEG_INF; c.sb = 0.f; c.se = 0.f; c.y = -1;
     if (t < Tb && u <= Ub) {
@@ -430,13 +445,15 @@ __global__ __launch_bounds__(1024) void k_lattice(
 
 void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, double *beta_s,
                     const int32_t *logit_lens, const int32_t *target_lens, float *costs, int B,
-                    int U1, int D, hipStream_t st)
+                    int U1, int D, unsigned *err, hipStream_t st)
 {
     const int NW = (U1 + 63) / 64;
     const size_t mbox = (size_t)(NW - 1) * D * 12;  // chain mailboxes: 8 B value + 4 B tag per boundary and step
     if (mbox <= 64 * 1024) {
+        if (NW > 1) (void)hipMemsetAsync(err, 0, 4, st);  // one wave: no mailbox, no spin
         hipLaunchKernelGGL(k_lattice_chain, dim3(B, 2), dim3(64 * NW), (mbox + 15) / 16 * 16, st, lpb_s, lpe_s, alpha_s,
-                           beta_s, logit_lens, target_lens, costs, U1, D);
+                           beta_s, logit_lens, target_lens, costs, U1, D, err);
+        if (NW > 1) hipLaunchKernelGGL(k_lattice_status, dim3(1), dim3(64), 0, st, err, costs, B);
         return;
     }
     const int NT = ((U1 + 63) / 64) * 64;

@@ -38,7 +38,17 @@ EXPORTS = (
     "rnnt_engine_joint_fwd", "rnnt_engine_loss_fwd_bwd", "rnnt_engine_joint_loss_fwd_bwd",
     "rnnt_engine_workspace_layout", "rnnt_engine_run_stage",
     "rnnt_engine_greedy_scan_workspace_bytes", "rnnt_engine_greedy_scan",
+    "rnnt_engine_joint_loss_fwd", "rnnt_engine_run_stages",
+    "rnnt_engine_joint_bwd_workspace_bytes", "rnnt_engine_joint_bwd",
 )
+
+# per-call kernel variants (include/rnnt_engine.h RNNT_VARIANT_*): bit-identical results
+VARIANT_SEPARATE_G = 32
+VARIANT_SEPARATE_HIDDEN = 64
+VARIANT_FWD_LDS_RING = 128
+VARIANT_FWD_ONE_WG_PER_TILE = 256
+STAGES_ALL = 255
+STAGES_FORWARD = 7  # operand producers + joint-forward GEMM + lattice sweep: costs only
 
 
 class WsLayout(ctypes.Structure):
@@ -114,9 +124,25 @@ def _require_cuda(*tensors):
     return dev
 
 
+def _require_dtype(dtype, **tensors):
+    """The C side reinterprets every pointer: a wrong element type would be read past its
+    allocation.  Raise instead."""
+    for name, t in tensors.items():
+        if t is not None and t.dtype != dtype:
+            raise RuntimeError(f"rnnt_amd: {name} must be {dtype} (got {t.dtype})")
+
+
+def _require_contiguous(**tensors):
+    for name, t in tensors.items():
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError(f"rnnt_amd: {name} must be contiguous")
+
+
 def workspace(device, nbytes):
-    """Grow-only per-device scratch buffer (torch owns the memory; 256-byte aligned)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, stream): work enqueued on two streams of one device
+    never shares scratch memory (torch owns the memory; 256-byte aligned)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, idx, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         _workspaces.pop(key, None)
@@ -150,34 +176,66 @@ def joint_fwd(enc, pred, W, bias):
     """logits[B,T,U1,V] = tanh(enc[:, :, None] + pred[:, None]) @ W.T + bias on the GPU
     (reference rnnt/joint.py:32-39).  `enc` may be a non-contiguous (B,T,H) view."""
     dev = _require_cuda(enc, pred, W, bias)
+    _require_dtype(torch.float32, enc=enc, pred=pred, W=W, bias=bias)
     B, T, H = enc.shape
     U1 = pred.shape[1]
     V = W.shape[0]
     pred, W, bias = pred.contiguous(), W.contiguous(), bias.contiguous()
-    logits = torch.empty((B, T, U1, V), dtype=torch.float32, device=dev)
-    n = ctypes.c_size_t(0)
-    _check(lib().rnnt_engine_joint_fwd_workspace_bytes(B, T, U1, H, V, DTYPE_F32, ctypes.byref(n)))
-    ws = workspace(dev, n.value)
-    _check(lib().rnnt_engine_joint_fwd(_p(enc), _strides3(enc), _p(pred), _p(W), _p(bias), B, T, U1,
-                                       H, V, DTYPE_F32, _p(logits), _p(ws),
-                                       ctypes.c_size_t(ws.numel()), _stream(dev)))
+    with torch.cuda.device(dev):
+        logits = torch.empty((B, T, U1, V), dtype=torch.float32, device=dev)
+        n = ctypes.c_size_t(0)
+        _check(lib().rnnt_engine_joint_fwd_workspace_bytes(B, T, U1, H, V, DTYPE_F32, ctypes.byref(n)))
+        ws = workspace(dev, n.value)
+        _check(lib().rnnt_engine_joint_fwd(_p(enc), _strides3(enc), _p(pred), _p(W), _p(bias), B, T, U1,
+                                           H, V, DTYPE_F32, _p(logits), _p(ws),
+                                           ctypes.c_size_t(ws.numel()), _stream(dev)))
     return logits
+
+
+def joint_bwd(enc, pred, W, grad_logits):
+    """Backward of joint_fwd on the engine (C ABI rnnt_engine_joint_bwd; autograd of reference
+    rnnt/joint.py:32-39): (grad_enc, grad_pred, grad_W, grad_bias) for an upstream gradient
+    `grad_logits` [B,T,U1,V]."""
+    dev = _require_cuda(enc, pred, W, grad_logits)
+    _require_dtype(torch.float32, enc=enc, pred=pred, W=W, grad_logits=grad_logits)
+    B, T, H = enc.shape
+    U1 = pred.shape[1]
+    V = W.shape[0]
+    if tuple(grad_logits.shape) != (B, T, U1, V):
+        raise RuntimeError("rnnt_amd.joint_bwd: grad_logits must be [B,T,U1,V]")
+    pred, W, grad_logits = pred.contiguous(), W.contiguous(), grad_logits.contiguous()
+    with torch.cuda.device(dev):
+        ge = torch.empty((B, T, H), dtype=torch.float32, device=dev)
+        gp = torch.empty((B, U1, H), dtype=torch.float32, device=dev)
+        gW = torch.empty((V, H), dtype=torch.float32, device=dev)
+        gb = torch.empty(V, dtype=torch.float32, device=dev)
+        n = ctypes.c_size_t(0)
+        _check(lib().rnnt_engine_joint_bwd_workspace_bytes(B, T, U1, H, V, DTYPE_F32, ctypes.byref(n)))
+        ws = workspace(dev, n.value)
+        _check(lib().rnnt_engine_joint_bwd(_p(enc), _strides3(enc), _p(pred), _p(W), _p(grad_logits), B, T,
+                                           U1, H, V, DTYPE_F32, _p(ge), _p(gp), _p(gW), _p(gb), _p(ws),
+                                           ctypes.c_size_t(ws.numel()), _stream(dev)))
+    return ge, gp, gW, gb
 
 
 def loss_fwd_bwd(logits, targets, logit_lens, target_lens, blank, clamp=-1.0, want_grad=True):
     """Per-utterance costs and d(sum costs)/d logits (reference rnnt/model.py:35-41)."""
     dev = _require_cuda(logits, targets, logit_lens, target_lens)
+    _require_dtype(torch.float32, logits=logits)
+    _require_dtype(torch.int32, targets=targets, logit_lens=logit_lens, target_lens=target_lens)
+    _require_contiguous(logits=logits, targets=targets, logit_lens=logit_lens, target_lens=target_lens)
     B, T, U1, V = logits.shape
     targets = _nonempty(targets)
-    costs = torch.empty(B, dtype=torch.float32, device=dev)
-    grad = torch.empty_like(logits) if want_grad else None
-    n = ctypes.c_size_t(0)
-    _check(lib().rnnt_engine_loss_workspace_bytes(B, T, U1, V, DTYPE_F32, ctypes.byref(n)))
-    ws = workspace(dev, n.value)
-    _check(lib().rnnt_engine_loss_fwd_bwd(_p(logits), _p(targets), _p(logit_lens), _p(target_lens),
-                                          B, T, U1, V, int(blank), ctypes.c_float(clamp), DTYPE_F32,
-                                          _p(costs), _p(grad), _p(ws), ctypes.c_size_t(ws.numel()),
-                                          _stream(dev)))
+    with torch.cuda.device(dev):
+        costs = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(logits) if want_grad else None
+        n = ctypes.c_size_t(0)
+        _check(lib().rnnt_engine_loss_workspace_bytes(B, T, U1, V, DTYPE_F32, ctypes.byref(n)))
+        ws = workspace(dev, n.value)
+        _check(lib().rnnt_engine_loss_fwd_bwd(_p(logits), _p(targets), _p(logit_lens), _p(target_lens),
+                                              B, T, U1, V, int(blank), ctypes.c_float(clamp), DTYPE_F32,
+                                              _p(costs), _p(grad), _p(ws), ctypes.c_size_t(ws.numel()),
+                                              _stream(dev)))
     return costs, grad
 
 
@@ -203,28 +261,75 @@ def alloc_fused_outputs(enc, pred, W):
             torch.empty(W.shape[0], dtype=torch.float32, device=dev))
 
 
+def _check_fused_inputs(enc, pred, W, bias, targets, logit_lens, target_lens):
+    dev = _require_cuda(enc, pred, W, bias, targets, logit_lens, target_lens)
+    _require_dtype(torch.float32, enc=enc, pred=pred, W=W, bias=bias)
+    _require_dtype(torch.int32, targets=targets, logit_lens=logit_lens, target_lens=target_lens)
+    _require_contiguous(pred=pred, W=W, bias=bias, targets=targets, logit_lens=logit_lens,
+                        target_lens=target_lens)
+    if enc.dim() != 3 or pred.dim() != 3 or W.dim() != 2 or bias.dim() != 1:
+        raise RuntimeError("rnnt_amd: enc [B,T,H], pred [B,U1,H], W [V,H], bias [V] expected")
+    B, T, H = enc.shape
+    if pred.shape[0] != B or pred.shape[2] != H or W.shape[1] != H or bias.shape[0] != W.shape[0]:
+        raise RuntimeError("rnnt_amd: enc / pred / W / bias shape mismatch")
+    if logit_lens.shape[0] != B or target_lens.shape[0] != B:
+        raise RuntimeError("rnnt_amd: length tensors must have B entries")
+    if targets.numel() and tuple(targets.shape) != (B, pred.shape[1] - 1):
+        raise RuntimeError("rnnt_amd: targets must be [B, U1-1]")
+    return dev
+
+
 def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
-                       outs=None, stage=None, dtype="fp32"):
+                       outs=None, stage=None, dtype="fp32", stage_mask=None, variant=0):
     """Fused joint + transducer loss forward AND backward (one C-ABI call).
     Returns (costs[B], grad_enc, grad_pred, grad_W, grad_bias); gradients are those of
-    grad_scale * sum_b costs[b].  `stage` (0..7) runs a single pipeline stage (bench aid).
+    grad_scale * sum_b costs[b].  `stage` (0..7) runs a single pipeline stage (bench aid);
+    `stage_mask` / `variant` run any subset of stages with per-call kernel variants (VARIANT_*).
     `dtype` "bf16": the three GEMMs take bf16-rounded operands (tensors stay fp32)."""
-    dev = _require_cuda(enc, pred, W, bias, targets, logit_lens, target_lens)
+    dev = _check_fused_inputs(enc, pred, W, bias, targets, logit_lens, target_lens)
     B, T, H = enc.shape
     U1 = pred.shape[1]
     V = W.shape[0]
     targets = _nonempty(targets)
-    if outs is None:
-        outs = alloc_fused_outputs(enc, pred, W)
-    code = dtype_code(dtype)
-    ws = workspace(dev, workspace_bytes(B, T, U1, H, V, code))
-    args = _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
-                       outs, ws, code)
-    if stage is None:
-        _check(lib().rnnt_engine_joint_loss_fwd_bwd(*args))
-    else:
-        _check(lib().rnnt_engine_run_stage(int(stage), *args))
+    with torch.cuda.device(dev):
+        if outs is None:
+            outs = alloc_fused_outputs(enc, pred, W)
+        else:
+            _require_cuda(enc, *outs)
+            _require_dtype(torch.float32, **{f"outs[{i}]": o for i, o in enumerate(outs)})
+            _require_contiguous(**{f"outs[{i}]": o for i, o in enumerate(outs)})
+        code = dtype_code(dtype)
+        ws = workspace(dev, workspace_bytes(B, T, U1, H, V, code))
+        args = _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
+                           outs, ws, code)
+        if stage_mask is not None or variant:
+            mask = STAGES_ALL if stage_mask is None else int(stage_mask)
+            _check(lib().rnnt_engine_run_stages(mask, int(variant), *args))
+        elif stage is None:
+            _check(lib().rnnt_engine_joint_loss_fwd_bwd(*args))
+        else:
+            _check(lib().rnnt_engine_run_stage(int(stage), *args))
     return outs
+
+
+def joint_loss_fwd(enc, pred, W, bias, targets, logit_lens, target_lens, blank, dtype="fp32"):
+    """Costs only (C ABI rnnt_engine_joint_loss_fwd): the fused path's forward — joint GEMM with
+    the log-softmax in its epilogue, lattice sweep — and none of the backward kernels or gradient
+    buffers.  What RNNTModel.forward costs under torch.no_grad()."""
+    dev = _check_fused_inputs(enc, pred, W, bias, targets, logit_lens, target_lens)
+    B, T, H = enc.shape
+    U1 = pred.shape[1]
+    V = W.shape[0]
+    targets = _nonempty(targets)
+    code = dtype_code(dtype)
+    with torch.cuda.device(dev):
+        costs = torch.empty(B, dtype=torch.float32, device=dev)
+        ws = workspace(dev, workspace_bytes(B, T, U1, H, V, code))
+        _check(lib().rnnt_engine_joint_loss_fwd(
+            _p(enc), _strides3(enc), _p(pred), _p(W), _p(bias), _p(targets), _p(logit_lens),
+            _p(target_lens), B, T, U1, H, V, int(blank), code, _p(costs), _p(ws),
+            ctypes.c_size_t(ws.numel()), _stream(dev)))
+    return costs
 
 
 GREEDY_SCAN_MAX_FRAMES = 128
@@ -238,19 +343,19 @@ def greedy_scan(enc, pred, W, bias, t0, nframes, blank):
     dev = _require_cuda(enc, pred, W, bias)
     if enc.dim() != 2 or pred.dim() != 1 or enc.shape[1] != pred.shape[0] or W.shape[1] != pred.shape[0]:
         raise RuntimeError("greedy_scan: enc [T,H], pred [H], W [V,H] expected")
-    if enc.dtype != torch.float32 or pred.dtype != torch.float32:
-        raise RuntimeError("greedy_scan: float32 tensors expected")
+    _require_dtype(torch.float32, enc=enc, pred=pred, W=W, bias=bias)
     T, H = enc.shape
     V = W.shape[0]
     nframes = int(nframes)
     if t0 < 0 or nframes < 1 or t0 + nframes > T:
         raise ValueError(f"greedy_scan: frames [{t0}, {t0 + nframes}) outside [0, {T})")
-    n = ctypes.c_size_t(0)
-    _check(lib().rnnt_engine_greedy_scan_workspace_bytes(nframes, H, V, ctypes.byref(n)))
-    ws = workspace(dev, n.value)
-    out = torch.empty(2 + nframes, dtype=torch.int32, device=dev)
-    _check(lib().rnnt_engine_greedy_scan(_p(enc), ctypes.c_int64(enc.stride(0)), ctypes.c_int64(enc.stride(1)),
-                                         _p(pred.contiguous()), _p(W.contiguous()), _p(bias.contiguous()),
-                                         int(t0), nframes, H, V, int(blank), _p(out), _p(ws),
-                                         ctypes.c_size_t(ws.numel()), _stream(dev)))
+    with torch.cuda.device(dev):
+        n = ctypes.c_size_t(0)
+        _check(lib().rnnt_engine_greedy_scan_workspace_bytes(nframes, H, V, ctypes.byref(n)))
+        ws = workspace(dev, n.value)
+        out = torch.empty(2 + nframes, dtype=torch.int32, device=dev)
+        _check(lib().rnnt_engine_greedy_scan(_p(enc), ctypes.c_int64(enc.stride(0)), ctypes.c_int64(enc.stride(1)),
+                                             _p(pred.contiguous()), _p(W.contiguous()), _p(bias.contiguous()),
+                                             int(t0), nframes, H, V, int(blank), _p(out), _p(ws),
+                                             ctypes.c_size_t(ws.numel()), _stream(dev)))
     return out

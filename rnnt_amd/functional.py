@@ -105,9 +105,10 @@ def _pad_hv(enc, pred, W, bias):
 
 
 class _JointLogits(torch.autograd.Function):
-    """Unfused joint: HIP forward (engine.joint_fwd).  Its backward is only reached when a
-    caller asks for the (B,T,U+1,V) logits AND differentiates through them — not the
-    training hot path (that is _JointRNNTLoss) — and is expressed with torch GPU ops."""
+    """Unfused joint: forward and backward both on the engine (rnnt_engine_joint_fwd /
+    rnnt_engine_joint_bwd).  The backward is reached when a caller keeps the (B,T,U+1,V) logits and
+    the loss as two calls — e.g. a maintainer who swaps only rnnt/joint.py — and differentiates
+    through them; the training hot path is _JointRNNTLoss."""
 
     @staticmethod
     def forward(ctx, enc, pred, W, bias):
@@ -117,21 +118,12 @@ class _JointLogits(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G):
         enc, pred, W = ctx.saved_tensors
-        ge = torch.zeros(enc.shape, dtype=enc.dtype, device=enc.device)
-        gp = torch.zeros_like(pred)
-        gW = torch.zeros_like(W)
-        for b in range(enc.shape[0]):  # one utterance at a time bounds the hidden tensor
-            hid = torch.tanh(enc[b].unsqueeze(1) + pred[b].unsqueeze(0))
-            dh = torch.matmul(G[b], W) * (1 - hid * hid)
-            ge[b] = dh.sum(1)
-            gp[b] = dh.sum(0)
-            gW += torch.matmul(G[b].reshape(-1, G.shape[-1]).t(), hid.reshape(-1, hid.shape[-1]))
-        return ge, gp, gW, G.sum((0, 1, 2))
+        return engine.joint_bwd(enc, pred, W, G)
 
 
 def joint_logits(enc, pred, W, bias):
     """logits = tanh(enc.unsqueeze(2) + pred.unsqueeze(1)) @ W.T + bias."""
-    if enc.dtype != torch.float32 or pred.dtype != torch.float32:
+    if any(t.dtype != torch.float32 for t in (enc, pred, W, bias)):
         raise RuntimeError("rnnt_amd.joint_logits: float32 inputs required")
     enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
     out = _JointLogits.apply(enc_p, pred_p, W_p, bias_p)
@@ -141,7 +133,12 @@ def joint_logits(enc, pred, W, bias):
 class _JointRNNTLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, pred, W, bias, targets, logit_lengths, target_lengths, blank, scale,
-                dtype="fp32"):
+                dtype="fp32", need_grad=True):
+        if not need_grad:  # torch.no_grad() / nothing requires grad: forward kernels only
+            costs = engine.joint_loss_fwd(enc, pred.contiguous(), W.contiguous(), bias.contiguous(),
+                                          targets, logit_lengths, target_lengths, blank, dtype=dtype)
+            ctx.mark_non_differentiable(costs)
+            return costs.sum() * scale, costs
         costs, ge, gp, gW, gb = engine.joint_loss_fwd_bwd(
             enc, pred.contiguous(), W.contiguous(), bias.contiguous(), targets, logit_lengths,
             target_lengths, blank, scale, dtype=dtype)
@@ -154,7 +151,7 @@ class _JointRNNTLoss(torch.autograd.Function):
     def backward(ctx, grad_loss, _grad_costs):
         ge, gp, gW, gb = ctx.saved_tensors
         return (ge * grad_loss, gp * grad_loss, gW * grad_loss, gb * grad_loss,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, blank=-1,
@@ -176,8 +173,8 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
         raise ValueError('reduction should be one of "none", "mean", or "sum"')
     if enc.dim() != 3 or pred.dim() != 3:
         raise RuntimeError("enc and pred must have 3 dimensions")
-    if enc.dtype != torch.float32 or pred.dtype != torch.float32:
-        raise RuntimeError("enc and pred must be float32 type")
+    if any(t.dtype != torch.float32 for t in (enc, pred, W, bias)):
+        raise RuntimeError("enc, pred, W and bias must be float32 type")
     B, T, _ = enc.shape
     U1 = pred.shape[1]
     V = W.shape[0]
@@ -191,6 +188,8 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
     else:
         enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
     scale = float(grad_scale) if grad_scale is not None else (1.0 / B if reduction == "mean" else 1.0)
+    # validation / eval (reference rnnt/train.py:170-201 runs the model under no_grad): costs only
+    need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (enc, pred, W, bias))
     loss, costs = _JointRNNTLoss.apply(enc_p, pred_p, W_p, bias_p, targets, logit_lengths,
-                                       target_lengths, blank, scale, code)
+                                       target_lengths, blank, scale, code, need_grad)
     return (loss, costs) if return_costs else loss

@@ -95,3 +95,36 @@ def oracle_fused_bf16(d):
     dpre = (Gb @ Wb).reshape(B, T, U1, H) * (1.0 - hidden * hidden)
     return dict(loss=costs.mean(), costs=costs, grad_enc=dpre.sum(2), grad_pred=dpre.sum(1),
                 grad_W=Gb.T @ hidden.reshape(-1, H), grad_bias=Gb.sum(0))
+
+
+# ---- published transducer known-answer vectors (tests/golden/published_transducer_kat.json):
+# third-party published unit-test data (warp-transducer / torchaudio), the nearest thing to a pin
+# of torchaudio.functional.rnnt_loss (reference rnnt/model.py:35-41) this image allows.
+def published_kat_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "published_transducer_kat.json")
+    out = []
+    for c in json.load(open(path))["cases"]:
+        shape = tuple(c["logits_shape"])
+        V = shape[-1]
+        case = dict(name=c["name"], blank=c["blank"], V=V,
+                    logits=np.asarray(c["logits"], dtype=np.float32).reshape(shape),
+                    targets=np.asarray(c["targets"], dtype=np.int32),
+                    logit_lens=np.asarray(c["logit_lengths"], dtype=np.int32),
+                    target_lens=np.asarray(c["target_lengths"], dtype=np.int32),
+                    costs=np.asarray(c["costs"], dtype=np.float64),
+                    grads=None if c["grads"] is None else np.asarray(c["grads"], dtype=np.float64).reshape(shape),
+                    grad_atol=c["grad_atol"])
+        out.append(case)
+        if c["blank"] == 0:
+            # the same case in the reference's convention (blank = -1 = V-1, rnnt/model.py:39): the
+            # loss is invariant under a relabelling of the vocabulary, here v -> v-1 (mod V)
+            r = dict(case)
+            r["name"] = c["name"] + "_rolled_to_blank_last"
+            r["blank"] = -1
+            r["logits"] = np.ascontiguousarray(np.roll(case["logits"], -1, axis=-1))
+            r["targets"] = (case["targets"] - 1).astype(np.int32)
+            r["grads"] = None if case["grads"] is None else np.roll(case["grads"], -1, axis=-1)
+            out.append(r)
+    return out

@@ -41,3 +41,21 @@ def test_committed_bf16_bench_line():
     d = _line("r01_bf16_bench_default.json")
     _check(d, "bf16")
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+
+
+def test_bench_refuses_to_run_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` with no launcher (WORLD_SIZE unset) starts the N ranks itself and
+    must exit non-zero — never fall through to a 1-GPU run — when fewer than N devices exist."""
+    import subprocess
+    import sys
+
+    import pytest
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has >= 2 GPUs: the self-launch would really run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "error" in line and line["n_gpus_requested"] == 2 and line["hipGetDeviceCount"] < 2

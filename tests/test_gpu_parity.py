@@ -9,7 +9,7 @@ import torch
 
 from tests.helpers import (BF16_GRAD_RTOL, BF16_GRAD_RTOL_EXACT, BF16_LOSS_RTOL,
                            BF16_LOSS_RTOL_EXACT, GRAD_RTOL, LOSS_RTOL, assert_close_grad, assert_close_loss,
-                           lgamma_paths_cost, make_inputs, oracle_fused, oracle_fused_bf16)
+                           lgamma_paths_cost, make_inputs, oracle_fused, oracle_fused_bf16, published_kat_cases)
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,9 @@ FUSED_SHAPES = [
     (1, 1, 0, 8, 4), (1, 1, 3, 8, 8), (2, 5, 0, 16, 8), (2, 5, 2, 16, 8), (3, 17, 8, 64, 32),
     (2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 12, 5, 128, 1024), (2, 40, 33, 72, 520),
     (2, 7, 3, 10, 7), (4, 30, 12, 520, 260), (1, 64, 40, 32, 1300),
+    # H > 512 (the reference's joint is 1024 wide): k_dhidden_gen covers columns 0-511, the
+    # persistent k_dhidden the rest (4-row t tiles: two dPred slab heights in one reduction)
+    (3, 21, 18, 1024, 64), (2, 10, 35, 768, 160), (2, 13, 6, 640, 1024), (2, 9, 4, 516, 96),
 ]
 
 
@@ -218,6 +221,26 @@ def test_loss_only_vs_oracle(amd, shape):
     assert_close_loss("mean", mean.item(), ref_c.mean())
 
 
+@pytest.mark.parametrize("case", published_kat_cases(), ids=lambda c: c["name"])
+def test_loss_matches_published_known_answers(amd, case):
+    """rnnt_amd.rnnt_loss — the drop-in for the torchaudio call at reference rnnt/model.py:35-41 —
+    against the published warp-transducer / torchaudio known-answer vectors (third-party published
+    unit-test data, tests/golden/published_transducer_kat.json): costs to 1e-6, gradients to 1e-6."""
+    lt = torch.from_numpy(case["logits"]).cuda().requires_grad_(True)
+    tg = torch.from_numpy(case["targets"]).cuda()
+    ll = torch.from_numpy(case["logit_lens"]).cuda()
+    tl = torch.from_numpy(case["target_lens"]).cuda()
+    costs = amd.rnnt_loss(lt, tg, ll, tl, blank=case["blank"], clamp=-1, reduction="none")
+    costs.sum().backward()
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), case["costs"], rtol=1e-6)
+    g = lt.grad.cpu().numpy().astype(np.float64)
+    if case["grads"] is not None:
+        assert np.abs(g - case["grads"]).max() <= max(case["grad_atol"], 1e-6)
+    assert np.abs(g.sum(-1)).max() < 1e-6
+    mean = amd.rnnt_loss(lt.detach(), tg, ll, tl, blank=case["blank"], reduction="mean")
+    np.testing.assert_allclose(mean.item(), case["costs"].mean(), rtol=1e-6)
+
+
 def test_loss_clamp(amd):
     from oracle import cpu_oracle
     rng = np.random.default_rng(3)
@@ -376,25 +399,110 @@ def test_fused_path_is_bitwise_reproducible(amd):
 
 @pytest.mark.parametrize("shape", [(3, 61, 23, 128, 260), (2, 300, 40, 512, 1024)])
 def test_forward_kernel_variants_agree_bitwise(amd, shape):
-    """The forward GEMM has switchable forms (rnnt_engine_set_flags): persistent workgroups with
-    register-streamed W fragments (default), 64: hidden from the separate k_make_hidden pass,
-    128: the LDS-DMA ring main loop, 256: one workgroup per tile.  They multiply the same numbers
-    in the same order, so every output must be identical bit for bit."""
+    """The pipeline has per-call kernel variants (rnnt_engine_run_stages, RNNT_VARIANT_*): forward
+    with persistent workgroups and register-streamed W fragments (default) / hidden from the
+    separate k_make_hidden pass / the LDS-DMA ring main loop / one workgroup per tile; G from the
+    separate k_make_g pass + the persistent dHidden kernel.  They multiply the same numbers in the
+    same order (the forward ones exactly; the dHidden variant sums its k chunks in a rotated order,
+    so it is held to the parity tolerance instead)."""
     B, T, U, H, V = shape
     d = make_inputs(B, T, U, H, V, seed=21)
     g = _dev(d)
-    lib = amd.engine.lib()
-    run = lambda: [o.clone() for o in amd.engine.joint_loss_fwd_bwd(
+    E = amd.engine
+    run = lambda variant: [o.clone() for o in E.joint_loss_fwd_bwd(
         g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"], g["target_lens"],
-        V - 1, 1.0 / B)]
-    try:
-        ref = run()
-        for flags in (64, 128, 256, 64 | 256):
-            lib.rnnt_engine_set_flags(flags)
-            for x, y in zip(run(), ref):
-                assert torch.equal(x, y), flags
-    finally:
-        lib.rnnt_engine_set_flags(0)
+        V - 1, 1.0 / B, variant=variant)]
+    ref = run(0)
+    for variant in (E.VARIANT_SEPARATE_HIDDEN, E.VARIANT_FWD_LDS_RING, E.VARIANT_FWD_ONE_WG_PER_TILE,
+                    E.VARIANT_SEPARATE_HIDDEN | E.VARIANT_FWD_ONE_WG_PER_TILE):
+        for x, y in zip(run(variant), ref):
+            assert torch.equal(x, y), variant
+    sep = run(E.VARIANT_SEPARATE_G)
+    assert torch.equal(sep[0], ref[0])  # costs: same forward
+    for x, y in zip(sep[1:], ref[1:]):
+        assert_close_grad("separate-G variant", x.cpu().numpy(), y.cpu().numpy())
+    # the shipped library has no process-wide switches: set_flags is a no-op
+    assert E.lib().rnnt_engine_set_flags(64 | 128 | 256) == 0
+    for x, y in zip(run(0), ref):
+        assert torch.equal(x, y)
+
+
+def test_forward_only_costs_match_and_skip_backward(amd):
+    """torch.no_grad() / no input requires grad: RNNTModel.forward's loss comes from the forward
+    kernels alone (rnnt_engine_joint_loss_fwd) and equals the training-mode loss bit for bit."""
+    d = make_inputs(3, 37, 11, 256, 256, seed=5)
+    g = _dev(d)
+    r = _run_fused(amd, d)
+    with torch.no_grad():
+        loss, costs = amd.joint_rnnt_loss(g["enc"].requires_grad_(True), g["pred"], g["W"], g["bias"],
+                                          g["targets"], g["logit_lens"], g["target_lens"], return_costs=True)
+    assert not loss.requires_grad
+    assert loss.item() == r["loss"] and np.array_equal(costs.cpu().numpy(), r["costs"])
+    loss2 = amd.joint_rnnt_loss(g["enc"].detach(), g["pred"], g["W"], g["bias"], g["targets"],
+                                g["logit_lens"], g["target_lens"])
+    assert loss2.item() == r["loss"] and not loss2.requires_grad
+    c3 = amd.engine.joint_loss_fwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"],
+                                   g["target_lens"], 255, dtype="bf16")
+    assert np.allclose(c3.cpu().numpy(), r["costs"], rtol=2e-2)
+
+
+def test_unfused_backward_runs_on_the_engine(amd):
+    """joint_logits(...).backward(): rnnt_engine_joint_bwd (autograd of rnnt/joint.py:32-39) against
+    plain torch ops in float64, with a random upstream gradient, a permuted encoder view, H > 512
+    and H / V that need host-side padding."""
+    for (B, T, U1, H, V) in ((2, 19, 7, 64, 40), (1, 33, 18, 640, 96), (2, 9, 5, 30, 10)):
+        torch.manual_seed(B + T + H)
+        enc_ct = torch.randn(B, H, T, device="cuda")
+        enc = enc_ct.permute(0, 2, 1).requires_grad_(True)
+        pred = torch.randn(B, U1, H, device="cuda", requires_grad=True)
+        W = (torch.randn(V, H, device="cuda") / H ** 0.5).requires_grad_(True)
+        bias = torch.randn(V, device="cuda", requires_grad=True)
+        up = torch.randn(B, T, U1, V, device="cuda")
+        out = amd.joint_logits(enc, pred, W, bias)
+        (out * up).sum().backward()
+        e64, p64, W64, b64 = (x.detach().double().requires_grad_(True) for x in (enc, pred, W, bias))
+        ref = torch.tanh(e64.unsqueeze(2) + p64.unsqueeze(1)) @ W64.T + b64
+        (ref * up.double()).sum().backward()
+        assert_close_grad("logits", out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5)
+        for name, a_, b_ in (("enc", enc, e64), ("pred", pred, p64), ("W", W, W64), ("bias", bias, b64)):
+            assert_close_grad(name, a_.grad.cpu().numpy(), b_.grad.cpu().numpy())
+
+
+def test_engine_rejects_wrong_dtypes(amd):
+    """The C side reinterprets pointers: a bf16 / fp64 / int64 tensor must raise, not be read past
+    its allocation."""
+    d = make_inputs(2, 6, 3, 16, 8, seed=1)
+    g = _dev(d)
+    args = [g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"], g["target_lens"], 7, 0.5]
+    for i, bad in ((2, g["W"].bfloat16()), (3, g["bias"].double()), (4, g["targets"].long()),
+                   (5, g["logit_lens"].long()), (0, g["enc"].half())):
+        a = list(args)
+        a[i] = bad
+        with pytest.raises(RuntimeError, match="must be torch"):
+            amd.engine.joint_loss_fwd_bwd(*a)
+    with pytest.raises(RuntimeError, match="must be torch"):
+        amd.engine.joint_fwd(g["enc"], g["pred"], g["W"].bfloat16(), g["bias"])
+    with pytest.raises(RuntimeError, match="float32"):
+        amd.joint_rnnt_loss(g["enc"], g["pred"], g["W"].bfloat16(), g["bias"], g["targets"],
+                            g["logit_lens"], g["target_lens"])
+
+
+def test_bad_lengths_are_clamped_on_the_device(amd):
+    """check_lengths=False (no host sync) with lengths outside the lattice: the kernels clamp what
+    they read (include/rnnt_engine.h), so the result is the loss of the clamped lattice, finite and
+    equal to the oracle on the clamped lengths — never an out-of-bounds access."""
+    d = make_inputs(3, 20, 70, 64, 32, seed=9)  # U1 = 71: two chained waves in the sweep
+    d["logit_lens"] = np.array([20, 99, 0], dtype=np.int32)
+    d["target_lens"] = np.array([70, -3, 500], dtype=np.int32)
+    g = _dev(d)
+    loss, costs = amd.joint_rnnt_loss(g["enc"], g["pred"], g["W"], g["bias"], g["targets"],
+                                      g["logit_lens"], g["target_lens"], check_lengths=False,
+                                      return_costs=True)
+    dc = dict(d)
+    dc["logit_lens"] = np.array([20, 20, 1], dtype=np.int32)
+    dc["target_lens"] = np.array([70, 0, 70], dtype=np.int32)
+    ref = oracle_fused(dc)
+    assert_close_loss("costs", costs.cpu().numpy(), ref["costs"])
 
 
 # ---------------------------------------------------------------- full-size properties
@@ -434,23 +542,57 @@ def test_fullsize_config5_large_vocab_closed_form(amd):
     amd.engine.release_workspaces()
 
 
-def test_fullsize_config2_fused_vs_unfused_subset(amd):
-    """Full T,U,H,V of config 2 on 2 utterances: fused engine path vs the unfused GPU path
-    (joint GEMM -> rnnt_loss kernels -> torch-op backward): independent backward arithmetic."""
-    d = make_inputs(2, 1000, 200, 512, 1024, seed=22)
+def _fused_vs_unfused(amd, d):
+    """Fused engine path vs the unfused GPU path (joint GEMM -> rnnt_loss kernels -> plain torch-op
+    backward of the joint, written out here): independent backward arithmetic on dense data."""
     r = _run_fused(amd, d)
     g = _dev(d)
-    enc = g["enc"].requires_grad_(True); pred = g["pred"].requires_grad_(True)
-    W = g["W"].requires_grad_(True); bias = g["bias"].requires_grad_(True)
-    logits = amd.joint_logits(enc, pred, W, bias)
+    logits = amd.joint_logits(g["enc"], g["pred"], g["W"], g["bias"]).requires_grad_(True)
     loss = amd.rnnt_loss(logits, g["targets"], g["logit_lens"], g["target_lens"], blank=-1)
     loss.backward()
+    G = logits.grad
+    del logits
+    ge = torch.zeros_like(g["enc"]); gp = torch.zeros_like(g["pred"]); gW = torch.zeros_like(g["W"])
+    gb = G.sum((0, 1, 2))
+    for b in range(G.shape[0]):  # joint.py:32-39 backwards, one utterance at a time (memory)
+        hid = torch.tanh(g["enc"][b].unsqueeze(1) + g["pred"][b].unsqueeze(0))
+        dh = torch.matmul(G[b], g["W"]) * (1 - hid * hid)
+        ge[b] = dh.sum(1); gp[b] = dh.sum(0)
+        gW += torch.matmul(G[b].reshape(-1, G.shape[-1]).t(), hid.reshape(-1, hid.shape[-1]))
+        del hid, dh
     assert_close_loss("loss", r["loss"], loss.item(), rtol=1e-5)
-    assert_close_grad("grad_enc", r["grad_enc"], enc.grad.cpu().numpy(), rtol=5e-4)
-    assert_close_grad("grad_pred", r["grad_pred"], pred.grad.cpu().numpy(), rtol=5e-4)
-    assert_close_grad("grad_W", r["grad_W"], W.grad.cpu().numpy(), rtol=5e-4)
-    assert_close_grad("grad_bias", r["grad_bias"], bias.grad.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_enc", r["grad_enc"], ge.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_pred", r["grad_pred"], gp.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_W", r["grad_W"], gW.cpu().numpy(), rtol=5e-4)
+    assert_close_grad("grad_bias", r["grad_bias"], gb.cpu().numpy(), rtol=5e-4)
+    assert np.abs(r["grad_enc"]).max() > 0 and np.abs(r["grad_pred"]).max() > 0
+    del G, ge, gp, gW
+    torch.cuda.empty_cache()
     amd.engine.release_workspaces()
+
+
+def test_fullsize_config2_fused_vs_unfused_subset(amd):
+    """Full T,U,H,V of config 2 on 2 utterances, dense random data."""
+    _fused_vs_unfused(amd, make_inputs(2, 1000, 200, 512, 1024, seed=22))
+
+
+def test_fullsize_config4_fused_vs_unfused_subset(amd):
+    """Full T,U,H,V of config 4 (T=4000,U=600,H=640,V=1024) on 1 utterance, dense random W: the
+    H > 512 backward (k_dhidden_gen for columns 0-511 + k_dhidden for 512-639), the barrier lattice
+    kernel (mailboxes > 64 KB) and the odd 128-column dW tile multiply non-zero data."""
+    _fused_vs_unfused(amd, make_inputs(1, 4000, 600, 640, 1024, seed=44))
+
+
+def test_fullsize_config5_fused_vs_unfused_subset(amd):
+    """Full T,U,H,V of config 5 (T=800,U=150,H=512,V=16384) on 2 ragged utterances, fp32 route,
+    dense random W: 32 forward column passes and 2048-chunk dHidden K loops on non-degenerate data."""
+    _fused_vs_unfused(amd, make_inputs(2, 800, 150, 512, 16384, seed=55))
+
+
+def test_fused_vs_unfused_reference_joint_width(amd):
+    """The reference's real joint width (hidden_features: 1024, rnnt/config/*.yaml) at BASELINE
+    config 1's plumbing shape scaled to a training batch: B=4,T=208,U=50,H=1024,V=1024, ragged."""
+    _fused_vs_unfused(amd, make_inputs(4, 208, 50, 1024, 1024, seed=11))
 
 
 # ---- bf16 route (BASELINE config 3).  (B, T, U, H, V): ragged, several u-blocks / t-tiles /
@@ -591,4 +733,22 @@ def test_fullsize_config2_softmax_shift_invariance(amd):
         assert_close_grad(k, r1[k], r0[k], rtol=2e-4)
     assert abs(r0["grad_bias"].sum()) < 1e-3 * np.abs(r0["grad_bias"]).sum()
     # per-utterance costs of ragged full-size inputs are positive and ordered by lattice size
+    assert (r0["costs"] > 0).all()
+
+
+def test_fullsize_config4_softmax_shift_invariance(amd):
+    """The same size-independent property at BASELINE config 4's FULL size (B=8,T=4000,U=600,H=640,
+    V=1024; 144 GB workspace, row offsets >> 2^31, ragged lengths) with dense random W."""
+    d = make_inputs(8, 4000, 600, 640, 1024, seed=78)
+    amd.engine.release_workspaces()
+    r0 = _run_fused(amd, d)
+    d2 = dict(d)
+    d2["bias"] = (d["bias"] - np.float32(1.75)).astype(np.float32)
+    r1 = _run_fused(amd, d2)
+    amd.engine.release_workspaces()
+    assert_close_loss("costs", r1["costs"], r0["costs"], rtol=2e-5)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r1[k], r0[k], rtol=2e-4)
+        assert np.abs(r0[k]).max() > 0
+    assert abs(r0["grad_bias"].sum()) < 1e-3 * np.abs(r0["grad_bias"]).sum()
     assert (r0["costs"] > 0).all()

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import brute_force, cpu_oracle, torch_check
-from tests.helpers import assert_close_grad, lgamma_paths_cost
+from tests.helpers import assert_close_grad, lgamma_paths_cost, published_kat_cases
 
 
 def _sd(z):
@@ -76,6 +76,21 @@ def test_oracle_e2e_matches_golden_from_reference_modules(golden_dir):
     np.testing.assert_allclose(r["grad_pred"], z["grad_text"], atol=1e-11)
     np.testing.assert_allclose(r["grad_W"], z["grad__joint_ln__weight"], atol=1e-11)
     np.testing.assert_allclose(r["grad_bias"], z["grad__joint_ln__bias"], atol=1e-11)
+
+
+@pytest.mark.parametrize("case", published_kat_cases(), ids=lambda c: c["name"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_oracle_loss_matches_published_known_answers(case, dtype):
+    """The loss half of the oracle against the published warp-transducer / torchaudio unit-test
+    vectors (third-party published data, provenance in the fixture): costs to 1e-6 relative,
+    d cost / d logits to the published precision."""
+    blank = case["blank"] if case["blank"] >= 0 else case["V"] + case["blank"]
+    costs, grad = cpu_oracle.rnnt_loss(case["logits"], case["targets"], case["logit_lens"],
+                                       case["target_lens"], blank=blank, dtype=dtype)
+    np.testing.assert_allclose(costs, case["costs"], rtol=1e-6)
+    if case["grads"] is not None:
+        assert np.abs(grad - case["grads"]).max() <= case["grad_atol"]
+    assert np.abs(grad.sum(-1)).max() < (1e-12 if dtype == np.float64 else 1e-6)
 
 
 @pytest.mark.parametrize("T,U,V,seed", [(1, 0, 4, 0), (1, 3, 5, 1), (4, 0, 5, 2), (4, 3, 5, 3),
