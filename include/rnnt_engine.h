@@ -45,7 +45,7 @@ extern "C" {
  * accumulation; the logits are kept in fp16 (workspace only; nearest-even, the loss is computed
  * from the stored values); log-softmax, the lattice and every reduction stay fp32/fp64.  Fused
  * entry only (rnnt_engine_joint_loss_fwd_bwd, rnnt_engine_run_stage, the workspace queries);
- * needs H % 128 == 0, H <= 512, V % 128 == 0. */
+ * needs H % 128 == 0, V % 128 == 0. */
 #define RNNT_DTYPE_BF16 1
 
 #define RNNT_OK 0

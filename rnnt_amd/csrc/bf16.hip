@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void k_pack_w_fwd_bf16(const float *__restrict
     out[idx] = o;
 }
 
-// dHidden B operand, fragment order: [c][s][tile(16)][lane] x 8 bf16,
-// element j = W[v = 32c + 16*(lane>>5) + 8s + j][h = 128*(tile>>2) + 4*(lane&31) + (tile&3)]
+// dHidden B operand, fragment order: [hp][c][s][tile(16)][lane] x 8 bf16 (hp = 512-column pass),
+// element j = W[v = 32c + 16*(lane>>5) + 8s + j][h = 512hp + 128*(tile>>2) + 4*(lane&31) + (tile&3)]
 __global__ __launch_bounds__(256) void k_pack_w_dh_bf16(const float *__restrict__ W,
                                                         u32x4 *__restrict__ out, int H, int V,
                                                         long n)
@@ -150,8 +150,9 @@ __global__ __launch_bounds__(256) void k_pack_w_dh_bf16(const float *__restrict_
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 15, s = (int)(idx >> 10) & 1;
-    const int c = (int)(idx >> 11);
-    const int h = 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
+    const int VC = V / 32;
+    const int c = (int)((idx >> 11) % VC), hp = (int)((idx >> 11) / VC);
+    const int h = 512 * hp + 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
     const int v0 = 32 * c + 16 * (lane >> 5) + 8 * s;
     u32x4 o = {0u, 0u, 0u, 0u};
     if (h < H) {
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_pack_w_dh_bf16(const float *__restrict_
 }
 
 size_t bf16_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 255) / 256) * (H / 32) * 2 * 8 * 64 * 16; }
-size_t bf16_wpack_dh_bytes(int V) { return (size_t)(V / 32) * 2 * 16 * 64 * 16; }
+size_t bf16_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V / 32) * 2 * 16 * 64 * 16; }
 
 void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
 {
@@ -174,7 +175,7 @@ void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
     const long nf = (long)(bf16_wpack_fwd_bytes(a.H, a.V) / 16);
     hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W,
                        (u32x4 *)a.wpack_fwd, a.H, a.V, a.H / 32, nf);
-    const long nd = (long)(bf16_wpack_dh_bytes(a.V) / 16);
+    const long nd = (long)(bf16_wpack_dh_bytes(a.H, a.V) / 16);
     hipLaunchKernelGGL(k_pack_w_dh_bf16, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a.W,
                        (u32x4 *)a.wpack_dh, a.H, a.V, nd);
 }
@@ -394,7 +395,7 @@ void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st)
 
 // ---------------------------------------------------------------------------------------
 // k_dhidden_bf16: G from the fp16 logits, stored as bf16 over its logits row (in place), and
-// dHidden = G . W over all H <= 512 columns; epilogue as the fp32 kernel: x (1 - hidden^2),
+// dHidden = G . W over 512 columns of H per launch; epilogue as the fp32 kernel: x (1 - hidden^2),
 // sum over u -> dEnc slab, sum over t -> dPred slab.  Tile = 8 t x 16 u cells.
 // 8 waves (two per SIMD, 128 accumulator registers each):
 //  * production: wave w turns t-row w of the tile into G: lane (u = l&15, quarter = l>>4) owns
@@ -408,11 +409,15 @@ void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st)
 //    A fragments from the exchange, B fragments from the staged W chunk (each wave copies
 //    4 KiB of it L2 -> VGPR -> LDS two chunks ahead).
 // One barrier per chunk publishes both.  grid (n_ublk, ceil(T/8), B), 512 threads.
-// Requires V % 128 == 0, H % 128 == 0, H <= 512.
+// Requires V % 128 == 0, H % 128 == 0.  One launch covers 512 columns of H: FIRST = true (columns
+// 0-511) is the kernel described above; H > 512 (the reference's joint is 1024 wide) adds one
+// FIRST = false launch per further 512 columns (`hp`), which finds G in place of the logits, copies
+// it into the exchange instead of producing it, and stores nothing but its slabs.
 // ---------------------------------------------------------------------------------------
 #define BG_BT 8
 #define BG_BU 16
-__global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
+template <bool FIRST>
+__global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int hp)
 {
     // [0, 64 KiB): W ring, 2 slots x [s(2)][tile(16)][lane(64)] x 16 B;  [64, 80 KiB): G exchange,
     // 2 slots x [M-tile(4)][s(2)][lane(64)] x 16 B.  The epilogue reuses all of it.
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     // workgroup-uniform: no products past the utterance's length or in a u block past U_b (no
     // lattice cell; the reductions skip its slabs), but k_dw_bf16 must find zeros in these rows
     if (t0 >= Tb || u0 > len_u(a.target_lens, b, a.U1)) {
-        if (pexists) {
+        if (FIRST && pexists) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             for (int c = 0; c < VC; ++c) grow[4 * c] = z;
         }
@@ -451,12 +456,13 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
     if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
     // rows outside the lattice read the zero padding row (finite) with c1 = -inf -> G = 0
-    const u32x4 *xsrc = (const u32x4 *)(live ? lrow : a.logits + zrow * V) + qd;  // chunk c: xsrc[4c]
+    // FIRST: fp16 logits of the live rows; later passes: the bf16 G every existing row now holds
+    const u32x4 *xsrc = (const u32x4 *)((FIRST ? live : pexists) ? lrow : a.logits + zrow * V) + qd;  // chunk c: xsrc[4c]
     const int blank = a.blank;
     // fragment image: MFMA s, lane (r, h) holds k = 16h + 8s + 0..7 of the chunk = quarter 2h + s
     // -> this lane's 16 B go to [M-tile wave>>1][s = qd&1][lane (qd>>1)*32 + 16*(wave&1) + r16]
     const int gdst = (wave >> 1) * 128 + (qd & 1) * 64 + (qd >> 1) * 32 + 16 * (wave & 1) + r16;
-    const u32x4 *wp = (const u32x4 *)a.wpack_dh + (wave * 4) * 64 + lane;  // this wave's 4 of the chunk's 32 pieces
+    const u32x4 *wp = (const u32x4 *)a.wpack_dh + (long)hp * VC * 2048 + (wave * 4) * 64 + lane;  // this wave's 4 of the chunk's 32 pieces
 
     f32x16 acc[8];
 #pragma unroll
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
         for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
 
     auto produce = [&](const u32x4 &x, int c, int slot) {
+        if constexpr (!FIRST) { s_g[slot * 512 + gdst] = x; return; }
         float g[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 2 * DEPTH, 0);
             }
-            if (!(q & 1) && !RNNT_XP(a.flags, 256)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
+            if (FIRST && !(q & 1) && !RNNT_XP(a.flags, 256)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
                 __builtin_amdgcn_sched_barrier(0);
                 const u32x4 gb0 = s_g[gsrc], gb1 = s_g[gsrc + 8];
                 if (gst_ok[0]) gst[0][4 * c] = gb0;
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a)
     if (RNNT_XP(a.flags, 8192)) return;
     float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
-    const int col0 = 128 * wn + 4 * j;
+    const int col0 = 512 * hp + 128 * wn + 4 * j;
     const bool colok = col0 < H;
     // All 32 hidden fragments of the epilogue requested up front through a raw buffer over the
     // tile's rows (scalar row offset + per-lane offset, no predicates: one memory round trip
@@ -656,7 +663,8 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
     // zero padding rows: G of rows k_dw_bf16 walks past the last cell, and the "dead row" source
     (void)hipMemsetAsync(a.logits + cells * a.V, 0, (size_t)(a.rows_alloc - cells) * a.V * 2, st);
     dim3 grid(a.n_ublk, (a.T + BG_BT - 1) / BG_BT, a.B);
-    hipLaunchKernelGGL(k_dhidden_bf16, grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_dhidden_bf16<true>, grid, dim3(512), 0, st, a, 0);
+    for (int hp = 1; hp * 512 < a.H; ++hp) hipLaunchKernelGGL(k_dhidden_bf16<false>, grid, dim3(512), 0, st, a, hp);
 }
 
 // ---------------------------------------------------------------------------------------

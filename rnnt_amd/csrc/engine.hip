@@ -46,8 +46,8 @@ int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
         return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (RNNT_DTYPE_F32 / RNNT_DTYPE_BF16)", dtype);
     if (dtype == RNNT_DTYPE_BF16 && !need_h)
         return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 only applies to the fused joint+loss entry");
-    if (dtype == RNNT_DTYPE_BF16 && (H <= 0 || H % 128 != 0 || H > 512 || V <= 0 || V % 128 != 0))
-        return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 needs H %% 128 == 0, H <= 512, V %% 128 == 0 (H=%d V=%d)", H, V);
+    if (dtype == RNNT_DTYPE_BF16 && (H <= 0 || H % 128 != 0 || V <= 0 || V % 128 != 0))
+        return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 needs H %% 128 == 0 and V %% 128 == 0 (H=%d V=%d)", H, V);
     if (B <= 0 || T <= 0 || U1 <= 0 || V <= 0 || (need_h && H <= 0))
         return fail(RNNT_ERR_INVALID_ARG, "non-positive dimension B=%d T=%d U1=%d H=%d V=%d", B, T, U1, H, V);
     if (V % 4 != 0) return fail(RNNT_ERR_UNSUPPORTED, "V=%d must be a multiple of 4 (pad on the host side)", V);
@@ -97,7 +97,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->beta_s = o;   o += align_up(skew * 8);
     L->coef = o;     o += align_up(cells * 16);
     L->wpack = o;
-    if (dtype == RNNT_DTYPE_BF16) o += align_up(bf16_wpack_fwd_bytes(H, V)) + align_up(bf16_wpack_dh_bytes(V));
+    if (dtype == RNNT_DTYPE_BF16) o += align_up(bf16_wpack_fwd_bytes(H, V)) + align_up(bf16_wpack_dh_bytes(H, V));
     else o += align_up(wpack_floats(H, V) * 4);
     L->enc_copy = o; o += align_up((size_t)B * T * H * 4);
     L->slab_enc = o; o += align_up((size_t)L->n_ublk * B * T * H * 4);
@@ -198,7 +198,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     g.grad_W = (float *)grad_W; g.grad_bias = (float *)grad_bias;
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
-    g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = xflags & ~16; g.debug = g_debug;
+    g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = xflags & ~16; g.debug = g_debug; g.pred_split_col = 0;
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;
         h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;
@@ -213,7 +213,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
         h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags;
         h.dw_tab = (long *)(ws + L.counters + 1024);
-        g.flags |= 16;  // reductions: dPred slabs are 8 t-rows high, as in k_dhidden_gen
+        g.pred_split_col = H;  // reductions: every dPred slab is 8 t-rows high, as in k_dhidden_gen
         if (stages & ST_PROD) launch_bf16_producers(h, st);
         if (stages & ST_FWD) launch_joint_fwd_bf16(h, st);  // softmax statistics in its epilogue
         if (stages & ST_LATTICE)
@@ -230,7 +230,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     }
     // G inside the dHidden GEMM unless the shape needs the separate pass (or flag 32 forces it)
     const bool fuse_g = dhidden_gen_ok(H, V, U1) && !(xflags & 32);
-    if (fuse_g) g.flags |= 16;
+    if (fuse_g) { g.flags |= 16; g.pred_split_col = 512; }  // k_dhidden_gen covers columns 0-511
 
     // hidden (A operand of all three GEMMs) is produced by the forward kernel for its own tile
     // unless flag 64 asks for the separate k_make_hidden pass

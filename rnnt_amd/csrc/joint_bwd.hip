@@ -223,8 +223,8 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a, int cb0)
 }
 
 // ---------------------------------------------------------------------------------------
-// k_dhidden_gen — dHidden GEMM that also PRODUCES G (replaces k_make_g + k_dhidden when one
-// workgroup covers all of H, i.e. H <= 512, and V % 32 == 0).
+// k_dhidden_gen — dHidden GEMM that also PRODUCES G (replaces k_make_g, and k_dhidden for the first
+// 512 columns of H — all of them when H <= 512; needs V % 32 == 0).
 //
 // k_make_g costs ~10 ms of pure HBM traffic (read 26 GB of logits, write 26 GB of G).  Here the
 // workgroup that owns a 128-cell tile (8 t x 16 u) reads the tile's logits once, turns them into
@@ -686,7 +686,7 @@ void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)
     const long n4p = (long)a.B * a.U1 * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_pred, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st,
                        a.slab_pred, a.logit_lens, a.target_lens, a.grad_pred, a.B, a.T, a.U1, a.H,
-                       (a.flags & 16) ? DG_BT : PW_BT, PW_BT, (a.flags & 16) ? DG_COLS : 0);
+                       DG_BT, PW_BT, a.pred_split_col);
 }
 
 // ---------------------------------------------------------------------------------------

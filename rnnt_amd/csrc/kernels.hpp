@@ -63,6 +63,7 @@ struct JointBwdArgs {
     long *dw_tab;       // 2B+2 longs: live-row table of k_dw (k_dw_table)
     int n_cu;           // compute units (grid size of the persistent kernels)
     int flags;          // bit 4 (16): G is produced by k_dhidden_gen; others: experiment switches
+    int pred_split_col; // dPred slabs: columns < this come in 8-row t tiles (k_dhidden_gen, bf16 route), the rest in 4-row tiles (k_dhidden)
     unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
 };
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
@@ -97,7 +98,7 @@ struct Bf16Args {
     long *dw_tab;  // 2B+2 longs: live-row table of k_dw_bf16 (k_dw_table, 32-cell granules)
 };
 size_t bf16_wpack_fwd_bytes(int H, int V);
-size_t bf16_wpack_dh_bytes(int V);
+size_t bf16_wpack_dh_bytes(int H, int V);
 void launch_bf16_producers(const Bf16Args &a, hipStream_t st);
 void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st);
 void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st);

@@ -164,7 +164,7 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
     enc, pred, W and bias.  enc [B,T,H] (any strides), pred [B,U+1,H], W [V,H], bias [V].
     `grad_scale` overrides the reduction factor (1/B_global when the batch is sharded).
     `dtype="bf16"` (BASELINE config 3): tensors stay fp32, the three GEMMs run on bf16-rounded
-    operands with fp32 accumulation; needs H % 128 == 0, H <= 512, V % 128 == 0."""
+    operands with fp32 accumulation; needs H % 128 == 0, V % 128 == 0."""
     if reduction not in ("mean", "sum"):
         if reduction == "none":
             raise NotImplementedError(

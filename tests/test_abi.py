@@ -78,16 +78,18 @@ def test_layout_is_consistent(lib):
 
 
 def test_bf16_dtype_queries_and_validation(lib):
-    """RNNT_DTYPE_BF16 (include/rnnt_engine.h): fused entry only, H % 128, H <= 512, V % 128."""
+    """RNNT_DTYPE_BF16 (include/rnnt_engine.h): fused entry only, H % 128, V % 128 (any H: 512-column passes)."""
     from rnnt_amd import engine
     lib.rnnt_engine_last_error.restype = ctypes.c_char_p
     n = ctypes.c_size_t(0)
     assert lib.rnnt_engine_workspace_bytes(32, 1000, 201, 512, 1024, 1, ctypes.byref(n)) == 0
     f32 = engine.workspace_bytes(32, 1000, 201, 512, 1024, "fp32")
     assert n.value == engine.workspace_bytes(32, 1000, 201, 512, 1024, "bf16") < f32  # bf16 hidden
-    for H, V in ((64, 128), (640, 1024), (512, 1000)):
+    for H, V in ((64, 128), (600, 1024), (512, 1000)):
         assert lib.rnnt_engine_workspace_bytes(2, 5, 3, H, V, 1, ctypes.byref(n)) == -2
         assert b"RNNT_DTYPE_BF16" in lib.rnnt_engine_last_error()
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 1024, 1024, 1, ctypes.byref(n)) == 0  # the reference's joint width
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 640, 1024, 1, ctypes.byref(n)) == 0
     # the standalone loss / joint entries have no bf16 variant
     assert lib.rnnt_engine_loss_workspace_bytes(2, 5, 3, 128, 1, ctypes.byref(n)) == -2
     L = engine.layout(3, 17, 9, 128, 256, "bf16")

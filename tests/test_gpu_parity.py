@@ -598,7 +598,9 @@ def test_fused_vs_unfused_reference_joint_width(amd):
 # ---- bf16 route (BASELINE config 3).  (B, T, U, H, V): ragged, several u-blocks / t-tiles /
 # forward passes / dW tiles and splits, dead tiles (t0 >= T_b), H < 512
 BF16_SHAPES = [(1, 1, 0, 128, 128), (2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024),
-               (4, 30, 12, 384, 256), (1, 70, 40, 128, 2048)]
+               (4, 30, 12, 384, 256), (1, 70, 40, 128, 2048),
+               # H > 512: one more k_dhidden_bf16 launch per further 512 columns (G read back in place)
+               (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128)]
 
 
 @pytest.mark.parametrize("shape", BF16_SHAPES)
