@@ -179,6 +179,36 @@ int rnnt_engine_greedy_scan(const void *enc, int64_t enc_stride_t, int64_t enc_s
                             void *stream);
 
 /*
+ * Gradient-norm clip + AdamW step over a list of fp32 tensors (next-step row SURVEY.md 8f-4): what
+ * follows loss.backward() in the reference's loop,
+ *     total_norm = torch.nn.utils.clip_grad_norm_(params, clip)        rnnt/train.py:136
+ *     optimizer.step()            torch.optim.AdamW(lr, betas, eps, weight_decay)   rnnt/train.py:164,
+ *                                 rnnt/config/basic_sp_convjs_fullcausal.yaml:82-87
+ * as multi-tensor kernels (pointer lists are HOST arrays of DEVICE pointers, packed into kernel
+ * arguments; up to 40 tensors per launch).
+ *   rnnt_engine_grad_norm   total_norm[0] (device) = 2-norm of all gradients, reduced in a fixed
+ *                           order; workspace from rnnt_engine_grad_norm_workspace_bytes.
+ *   rnnt_engine_adamw_step  decoupled weight decay, no amsgrad: p *= 1 - lr*wd; m += (1-b1)(g-m);
+ *                           v = b2 v + (1-b2) g^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).
+ *                           The hyper-parameters are doubles: their scalar arithmetic (1-b1, 1-b2,
+ *                           1-lr*wd, the bias corrections) is done in double, as torch does with python
+ *                           floats.  `step` = the update count including this one (>= 1).  When `total_norm`
+ *                           (device scalar) is non-NULL and max_norm > 0, every gradient is first
+ *                           scaled by min(1, max_norm / (total_norm + 1e-6)) — clip_grad_norm_'s
+ *                           coefficient, read on the device: no host synchronisation between
+ *                           backward and step; write_clipped_grads != 0 also stores the scaled
+ *                           gradients (clip_grad_norm_ works in place).
+ */
+int rnnt_engine_grad_norm_workspace_bytes(int n_tensors, const int64_t *numels, size_t *out);
+int rnnt_engine_grad_norm(int n_tensors, const void *const *grads, const int64_t *numels,
+                          float *total_norm, void *workspace, size_t ws_bytes, void *stream);
+int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const *grads,
+                           void *const *exp_avg, void *const *exp_avg_sq, const int64_t *numels,
+                           double lr, double beta1, double beta2, double eps, double weight_decay,
+                           int64_t step, const float *total_norm, float max_norm,
+                           int write_clipped_grads, void *stream);
+
+/*
  * Diagnostic view of the last fused call's intermediate buffers inside `workspace`
  * (offsets in bytes; valid for the dims given).  Used by tests and bench.py to time or
  * inspect single stages; not needed by training code.

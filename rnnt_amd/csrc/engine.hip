@@ -26,7 +26,10 @@ constexpr int g_flags = 0;
 constexpr unsigned long long *g_debug = nullptr;
 #endif
 
-int fail(int code, const char *fmt, ...)
+}  // namespace
+
+// record the calling thread's error message (rnnt_engine_last_error) and hand the code back
+int engine_fail(int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -36,6 +39,9 @@ int fail(int code, const char *fmt, ...)
     g_err = buf;
     return code;
 }
+
+namespace {
+#define fail engine_fail
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }

@@ -2,6 +2,9 @@
 #pragma once
 #include "common.hpp"
 
+// ---- engine.hip: sets the thread-local error message, returns `code`
+int engine_fail(int code, const char *fmt, ...);
+
 // ---- lattice.hip
 void launch_logsoftmax_gather(const float *logits, const int32_t *targets,
                               const int32_t *logit_lens, const int32_t *target_lens,

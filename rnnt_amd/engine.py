@@ -40,6 +40,7 @@ EXPORTS = (
     "rnnt_engine_greedy_scan_workspace_bytes", "rnnt_engine_greedy_scan",
     "rnnt_engine_joint_loss_fwd", "rnnt_engine_run_stages",
     "rnnt_engine_joint_bwd_workspace_bytes", "rnnt_engine_joint_bwd",
+    "rnnt_engine_grad_norm_workspace_bytes", "rnnt_engine_grad_norm", "rnnt_engine_adamw_step",
 )
 
 # per-call kernel variants (include/rnnt_engine.h RNNT_VARIANT_*): bit-identical results

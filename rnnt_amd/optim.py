@@ -1,0 +1,145 @@
+"""Gradient-norm clip + AdamW on the HIP engine: the two statements that
+follow loss.backward() in the reference's loop,
+
+    total_norm = torch.nn.utils.clip_grad_norm_(params, cfg.training.clip_grad_norm)   # rnnt/train.py:136
+    optimizer.step()      # torch.optim.AdamW(lr, betas, eps, weight_decay)             # rnnt/train.py:164
+
+as multi-tensor kernels reached through the C ABI (rnnt_engine_grad_norm, rnnt_engine_adamw_step):
+one launch per 40 parameter tensors instead of one per tensor, and the clip coefficient is read on
+the device, so nothing synchronises with the host between backward and step.
+
+    optimizer:                       # rnnt/config/*.yaml training.optimizer
+      _target_: rnnt_amd.optim.AdamW
+      lr: 3e-4 ...
+
+Reference behaviour kept: `clip_grad_norm_` given an exhausted generator (rnnt/train.py:95 makes
+`params` a generator that the optimizer's constructor consumes, train.py:104) clips nothing and
+returns 0, exactly like torch's.  fp32 CUDA/HIP parameters only; anything else raises.
+"""
+import ctypes
+from typing import Iterable, List
+
+import torch
+
+from . import engine
+
+__all__ = ["AdamW", "clip_grad_norm_"]
+
+
+def _ptr_array(tensors: List[torch.Tensor]):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _numel_array(tensors: List[torch.Tensor]):
+    return (ctypes.c_int64 * len(tensors))(*[t.numel() for t in tensors])
+
+
+def _check_group(tensors: List[torch.Tensor], what: str):
+    dev = tensors[0].device
+    for t in tensors:
+        if t.device.type != "cuda" or t.device != dev:
+            raise RuntimeError(f"rnnt_amd.optim: {what} must all live on one HIP device (got {t.device})")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"rnnt_amd.optim: {what} must be float32 (got {t.dtype})")
+        if not t.is_contiguous():
+            raise RuntimeError(f"rnnt_amd.optim: {what} must be contiguous")
+    return dev
+
+
+def grad_norm(grads: List[torch.Tensor]) -> torch.Tensor:
+    """2-norm of all `grads` as a 0-dim device tensor (no host sync)."""
+    dev = _check_group(grads, "gradients")
+    lib = engine.lib()
+    with torch.cuda.device(dev):
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        n = ctypes.c_size_t(0)
+        numels = _numel_array(grads)
+        engine._check(lib.rnnt_engine_grad_norm_workspace_bytes(len(grads), numels, ctypes.byref(n)))
+        ws = torch.empty(int(n.value), dtype=torch.uint8, device=dev)  # caching allocator: no sync
+        engine._check(lib.rnnt_engine_grad_norm(len(grads), _ptr_array(grads), numels, engine._p(out),
+                                                engine._p(ws), ctypes.c_size_t(ws.numel()),
+                                                engine._stream(dev)))
+    return out[0]
+
+
+def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm) (norm_type 2) on the engine: returns the
+    total norm (0-dim device tensor) and scales every .grad in place by
+    min(1, max_norm / (total_norm + 1e-6))."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if len(grads) == 0:  # also the reference's exhausted generator: nothing to clip, norm 0
+        return torch.tensor(0.0)
+    total = grad_norm(grads)
+    coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
+    torch._foreach_mul_(grads, coef)
+    return total
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW(params, lr, betas, eps, weight_decay) — decoupled weight decay, no amsgrad,
+    no maximize — whose step() is one multi-tensor engine call per parameter group.
+
+    `max_grad_norm` (optional, > 0) fuses clip_grad_norm_ into step(): the gradient norm of ALL
+    groups is reduced on the device and every gradient is scaled by min(1, max/(norm+1e-6)) on its
+    way into the moments — the clip the reference meant at rnnt/train.py:136 — without touching the
+    host.  `last_grad_norm` then holds the device scalar."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 max_grad_norm=None):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
+            raise ValueError("rnnt_amd.optim.AdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = engine.lib()
+        total = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            allg = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+            if allg:
+                total = grad_norm(allg)
+                self.last_grad_norm = total
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            gs = [p.grad for p in ps]
+            if any(g.is_sparse for g in gs):
+                raise RuntimeError("rnnt_amd.optim.AdamW does not support sparse gradients")
+            dev = _check_group(ps, "parameters")
+            _check_group(gs, "gradients")
+            ms, vs = [], []
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                ms.append(st["exp_avg"])
+                vs.append(st["exp_avg_sq"])
+            steps = {self.state[p]["step"] for p in ps}
+            # parameters that joined later (or skipped steps without a gradient) carry their own
+            # bias corrections: one engine call per distinct step count
+            for step in sorted(steps):
+                idx = [i for i, p in enumerate(ps) if self.state[p]["step"] == step]
+                sel = lambda xs: [xs[i] for i in idx]
+                b1, b2 = group["betas"]
+                with torch.cuda.device(dev):
+                    engine._check(lib.rnnt_engine_adamw_step(
+                        len(idx), _ptr_array(sel(ps)), _ptr_array(sel(gs)), _ptr_array(sel(ms)),
+                        _ptr_array(sel(vs)), _numel_array(sel(ps)), ctypes.c_double(group["lr"]),
+                        ctypes.c_double(b1), ctypes.c_double(b2), ctypes.c_double(group["eps"]),
+                        ctypes.c_double(group["weight_decay"]), ctypes.c_int64(int(step)),
+                        engine._p(total) if total is not None else ctypes.c_void_p(0),
+                        ctypes.c_float(self.max_grad_norm if total is not None else -1.0), 1,
+                        engine._stream(dev)))
+        return loss

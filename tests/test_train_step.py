@@ -81,7 +81,9 @@ def test_train_step_sequence_ddp_world1(hidden, proj):
         model = rnnt_amd.RNNTModel(_Predictor(vocab, feats), _Encoder(n_mels, feats), joint).to(device)
         _ddp_model = DDP(model, device_ids=[rank])  # train.py:68
         params = model.parameters()                  # train.py:95 (a generator, as in the reference)
-        optimizer = torch.optim.AdamW(params, lr=2e-3, weight_decay=1e-2)
+        # the optimizer of the yaml (`_target_: torch.optim.AdamW`) or its engine drop-in
+        opt_cls = rnnt_amd.optim.AdamW if proj else torch.optim.AdamW
+        optimizer = opt_cls(params, lr=2e-3, weight_decay=1e-2)
         lr_scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: min(1.0, (s + 1) / 5))
         _ddp_model.train()
         blank_idx, max_joint_size, clip = vocab - 1, 600, 10.0
