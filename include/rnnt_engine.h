@@ -209,6 +209,53 @@ int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const
                            int write_clipped_grads, void *stream);
 
 /*
+ * ConvPredictor forward / backward (next-step row SURVEY.md 8f-3): reference rnnt/predictor.py:189-229
+ * — embedding, LayerNorm, CausalConv1d k=3 + GELU + dropout, CausalConv1d k=5 + GELU + dropout
+ * (rnnt/causalconv.py:9-32: left zero padding), Linear, LayerNorm — on rows (b,u) with channels
+ * contiguous: the two permutes of predictor.py:216,225 are never materialised, each convolution is
+ * one MFMA GEMM per tap.  All pointers fp32 device pointers, 16-byte aligned; E % 4 == 0, O % 4 == 0.
+ *   ids [B,U1] int64 (as the reference passes them, rnnt/model.py:20-21); out [B,U1,O];
+ *   keep1 / keep2 [B,U1,E] bytes: dropout keep masks drawn by the caller (NULL = eval mode), kept
+ *   values are scaled by 1/(1-dropout_p);  ln_eps: torch.nn.LayerNorm's eps (1e-5);
+ *   `saved`: caller-owned buffer (rnnt_engine_conv_predictor_saved_bytes) the forward fills and the
+ *   backward of the SAME call reads; `g`: where each parameter's gradient is written (same field
+ *   order as the parameters; every gradient is overwritten, not accumulated).
+ */
+typedef struct rnnt_conv_predictor_params {
+    const float *embedding;           /* [S,E]                 embedding.weight           */
+    const float *ln_in_w, *ln_in_b;   /* [E]                   input_layer_norm.*         */
+    const float *conv1_w, *conv1_b;   /* [E,E,3], [E]          conv1.conv.* (Conv1d layout) */
+    const float *conv2_w, *conv2_b;   /* [E,E,5], [E]          conv2.conv.*               */
+    const float *linear_w, *linear_b; /* [O,E], [O]            linear.*                   */
+    const float *ln_out_w, *ln_out_b; /* [O]                   output_layer_norm.*        */
+} rnnt_conv_predictor_params;
+
+int rnnt_engine_conv_predictor_saved_bytes(int B, int U1, int S, int E, int O, size_t *out);
+int rnnt_engine_conv_predictor_fwd(const int64_t *ids, int B, int U1, int S, int E, int O,
+                                   const rnnt_conv_predictor_params *p, const uint8_t *keep1,
+                                   const uint8_t *keep2, float dropout_p, float ln_eps, float *out,
+                                   void *saved, size_t saved_bytes, void *stream);
+int rnnt_engine_conv_predictor_bwd(const int64_t *ids, int B, int U1, int S, int E, int O,
+                                   const rnnt_conv_predictor_params *p, const uint8_t *keep1,
+                                   const uint8_t *keep2, float dropout_p, const float *grad_out,
+                                   const rnnt_conv_predictor_params *g, void *saved, size_t saved_bytes,
+                                   void *stream);
+
+/*
+ * y = x W^T + b and its backward as MFMA kernels: the joint's optional input projections
+ * audio_ln / text_ln (next-step row SURVEY.md 8f-1; reference rnnt/joint.py:8-12,26-30).
+ * x [M,K] with rows ldx floats apart, W [N,K] (torch.nn.Linear layout), y / dy [M,N] contiguous.
+ * Backward: dW [N,K] = dy^T x, db [N] = column sums of dy (NULL: skipped), dx [M,K] = dy W (NULL:
+ * skipped).  K % 4 == 0, N % 4 == 0.
+ */
+int rnnt_engine_linear_fwd(const float *x, int64_t ldx, const float *W, const float *bias, int M, int K,
+                           int N, float *y, void *stream);
+int rnnt_engine_linear_bwd_workspace_bytes(int M, int K, int N, size_t *out);
+int rnnt_engine_linear_bwd(const float *x, int64_t ldx, const float *W, const float *dy, int M, int K,
+                           int N, float *dx, float *dW, float *db, void *workspace, size_t ws_bytes,
+                           void *stream);
+
+/*
  * Diagnostic view of the last fused call's intermediate buffers inside `workspace`
  * (offsets in bytes; valid for the dims given).  Used by tests and bench.py to time or
  * inspect single stages; not needed by training code.

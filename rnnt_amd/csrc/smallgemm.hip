@@ -1,0 +1,289 @@
+// smallgemm.hip — see smallgemm.hpp.  Used by predictor.hip (ConvPredictor forward / backward,
+// reference rnnt/predictor.py:189-229) and the joint's input projections (rnnt/joint.py:26-30).
+#include "smallgemm.hpp"
+
+namespace {
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// acc += the other waves' partial tiles, through `red` (NT tiles x 1024 floats): rounds 1..3, wave
+// w publishes, wave 0 adds.  Ends with every wave past the last barrier.
+template <int NTILES>
+__device__ __forceinline__ void reduce_to_wave0(f32x16 (&acc)[NTILES], float *red, int wave, int lane)
+{
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- NT: wave tile 32 rows x 128 columns (4 tiles of 32 columns); grid (ceil(N/128), ceil(M/32))
+__global__ __launch_bounds__(256) void k_sgemm_nt(SgArgs a)
+{
+    __shared__ float red[4 * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int M = a.M, N = a.N, K = a.K;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 128;
+    const int row = min(m0 + i, M - 1), u = row % a.seg;
+    const int KC = (K + 7) / 8, total = a.taps * KC;
+    long wrow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wrow[q] = (long)min(n0 + 32 * q + i, N - 1) * a.ldb;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    struct Ops { f32x4 x, w[4]; };
+    auto load = [&](Ops &o, int c) {
+        const int tap = c / KC, kc = c - tap * KC;
+        const int k = 8 * kc + 4 * half;
+        const bool kok = k < K;
+        const int kk = kok ? k : K - 4;
+        const int shift = tap - (a.taps - 1);
+        const bool rok = u + shift >= 0;
+        o.x = *(const f32x4 *)(a.A + (long)(rok ? row + shift : row) * a.lda + kk);
+        if (!rok || !kok) o.x = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *wt = a.B + (long)tap * N * a.ldb + kk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o.w[q] = *(const f32x4 *)(wt + wrow[q]);
+    };
+    auto compute = [&](const Ops &o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.x[s], o.w[q][s], acc[q], 0, 0, 0);
+    };
+    if (wave < total) {
+        Ops cur, nxt;
+        load(cur, wave);
+        for (int c = wave; c < total; c += 4) {
+            if (c + 4 < total) load(nxt, c + 4);
+            compute(cur);
+            cur = nxt;
+        }
+    }
+    reduce_to_wave0<4>(acc, red, wave, lane);
+    if (wave != 0) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n0 + 32 * q + i;
+        if (n >= N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= M) continue;
+            float v = acc[q][r] + bv;
+            if (a.Cpre) a.Cpre[(long)m * a.ldc + n] = v;
+            if (a.act == 1) v = gelu_exact(v);
+            if (a.mask) v = a.mask[(long)m * N + n] ? v * a.mask_scale : 0.f;
+            a.C[(long)m * a.ldc + n] = v;
+        }
+    }
+}
+
+// ---- NN: wave tile 32 rows x 128 columns (4 interleaved tiles: columns c0 + 4j + q)
+__global__ __launch_bounds__(256) void k_sgemm_nn(SgArgs a)
+{
+    __shared__ float red[4 * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int M = a.M, N = a.N, Kc = a.K;
+    const int m0 = blockIdx.y * 32, c0 = blockIdx.x * 128;
+    const int row = min(m0 + i, M - 1), u = row % a.seg;
+    const int KC = (Kc + 7) / 8, total = a.taps * KC;
+    const bool cok = c0 + 4 * i < N;
+    const int col = cok ? c0 + 4 * i : N - 4;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    struct Ops { f32x4 y, w[4]; };
+    auto load = [&](Ops &o, int c) {
+        const int tap = c / KC, kc = c - tap * KC;
+        const int k = 8 * kc + 4 * half;
+        const bool kok = k < Kc;
+        const int kk = kok ? k : Kc - 4;
+        const int shift = (a.taps - 1) - tap;
+        const bool rok = u + shift < a.seg && row + shift < M;
+        o.y = *(const f32x4 *)(a.A + (long)(rok ? row + shift : row) * a.lda + kk);
+        if (!rok || !kok) o.y = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *wt = a.B + ((long)tap * Kc + kk) * a.ldb + col;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o.w[s] = *(const f32x4 *)(wt + (long)s * a.ldb);
+    };
+    auto compute = [&](const Ops &o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y[s], o.w[s][q], acc[q], 0, 0, 0);
+    };
+    if (wave < total) {
+        Ops cur, nxt;
+        load(cur, wave);
+        for (int c = wave; c < total; c += 4) {
+            if (c + 4 < total) load(nxt, c + 4);
+            compute(cur);
+            cur = nxt;
+        }
+    }
+    reduce_to_wave0<4>(acc, red, wave, lane);
+    if (wave != 0 || !cok) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= M) continue;
+        const f32x4 o = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        *(f32x4 *)(a.C + (long)m * a.ldc + col) = o;
+    }
+}
+
+// ---- TN: wave tile 128 x 128 (4 x 4 interleaved tiles: rows n0 + 4i + qm, columns k0 + 4j + qn);
+// grid (ceil(K/128), ceil(N/128), taps)
+__global__ __launch_bounds__(256, 1) void k_sgemm_tn(SgArgs a)
+{
+    __shared__ float red[16 * 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int Mc = a.M, N = a.N, K = a.K;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, tap = blockIdx.z;
+    const bool nok = n0 + 4 * i < N, kok = k0 + 4 * i < K;
+    const int ncol = nok ? n0 + 4 * i : N - 4, kcol = kok ? k0 + 4 * i : K - 4;
+    const int shift = tap - (a.taps - 1);
+    const int steps = (Mc + 1) / 2;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
+
+    struct Ops { f32x4 y, x; };
+    auto load = [&](Ops &o, int ks) {
+        const int m = 2 * ks + half;
+        const bool mok = m < Mc;
+        const int mm = mok ? m : Mc - 1;
+        const bool xok = mok && (mm % a.seg) + shift >= 0;
+        o.y = *(const f32x4 *)(a.A + (long)mm * a.lda + ncol);
+        o.x = *(const f32x4 *)(a.B + (long)(xok ? mm + shift : mm) * a.ldb + kcol);
+        if (!xok) o.x = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!mok) o.y = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute = [&](const Ops &o) {
+#pragma unroll
+        for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 4; ++qn)
+                acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y[qm], o.x[qn], acc[qm][qn], 0, 0, 0);
+    };
+    if (wave < steps) {
+        Ops cur, nxt;
+        load(cur, wave);
+        for (int ks = wave; ks < steps; ks += 4) {
+            if (ks + 4 < steps) load(nxt, ks + 4);
+            compute(cur);
+            cur = nxt;
+        }
+    }
+    reduce_to_wave0<16>(reinterpret_cast<f32x16(&)[16]>(acc), red, wave, lane);
+    if (wave != 0 || !kok) return;
+#pragma unroll
+    for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * half) + qm;
+            if (n >= N) continue;
+            const f32x4 o = {acc[qm][0][r], acc[qm][1][r], acc[qm][2][r], acc[qm][3][r]};
+            *(f32x4 *)(a.C + ((long)tap * N + n) * a.ldc + kcol) = o;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_pack_conv_w(const float *__restrict__ w, float *__restrict__ wp,
+                                                     int out_c, int in_c, int taps, int unpack)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)out_c * in_c * taps;
+    if (idx >= n) return;
+    // idx walks the torch layout [out][in][tap]
+    const int t = (int)(idx % taps);
+    const long oi = idx / taps;
+    const int ci = (int)(oi % in_c), co = (int)(oi / in_c);
+    const long pidx = ((long)t * out_c + co) * in_c + ci;
+    if (unpack) const_cast<float *>(w)[idx] = wp[pidx];
+    else wp[pidx] = w[idx];
+}
+
+// stage 1: slab s sums rows [64s, 64s+64) of 256 columns; stage 2 sums the slabs
+__global__ __launch_bounds__(256) void k_colsum1(const float *__restrict__ Y, long ldy, int M, int N,
+                                                 float *__restrict__ scratch)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * 64, m1 = min(m0 + 64, M);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += Y[(long)m * ldy + n];
+    scratch[(long)blockIdx.y * N + n] = s;
+}
+__global__ __launch_bounds__(256) void k_colsum2(const float *__restrict__ scratch, int nslab, int N,
+                                                 float *__restrict__ out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += scratch[(long)k * N + n];
+    out[n] = s;
+}
+
+}  // namespace
+
+void launch_sgemm_nt(const SgArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sgemm_nt, dim3((a.N + 127) / 128, (a.M + 31) / 32), dim3(256), 0, st, a);
+}
+void launch_sgemm_nn(const SgArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sgemm_nn, dim3((a.N + 127) / 128, (a.M + 31) / 32), dim3(256), 0, st, a);
+}
+void launch_sgemm_tn(const SgArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sgemm_tn, dim3((a.K + 127) / 128, (a.N + 127) / 128, a.taps), dim3(256), 0, st, a);
+}
+void launch_pack_conv_w(const float *w, float *wp, int out_c, int in_c, int taps, hipStream_t st)
+{
+    const long n = (long)out_c * in_c * taps;
+    hipLaunchKernelGGL(k_pack_conv_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wp, out_c, in_c, taps, 0);
+}
+void launch_unpack_conv_w(const float *wp, float *w, int out_c, int in_c, int taps, hipStream_t st)
+{
+    const long n = (long)out_c * in_c * taps;
+    hipLaunchKernelGGL(k_pack_conv_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, const_cast<float *>(wp), out_c, in_c, taps, 1);
+}
+size_t colsum_scratch_floats(int M, int N) { return (size_t)((M + 63) / 64) * N; }
+void launch_colsum(const float *Y, long ldy, int M, int N, float *out, float *scratch, hipStream_t st)
+{
+    const int nslab = (M + 63) / 64;
+    hipLaunchKernelGGL(k_colsum1, dim3((N + 255) / 256, nslab), dim3(256), 0, st, Y, ldy, M, N, scratch);
+    hipLaunchKernelGGL(k_colsum2, dim3((N + 255) / 256), dim3(256), 0, st, scratch, nslab, N, out);
+}

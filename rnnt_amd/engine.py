@@ -41,6 +41,9 @@ EXPORTS = (
     "rnnt_engine_joint_loss_fwd", "rnnt_engine_run_stages",
     "rnnt_engine_joint_bwd_workspace_bytes", "rnnt_engine_joint_bwd",
     "rnnt_engine_grad_norm_workspace_bytes", "rnnt_engine_grad_norm", "rnnt_engine_adamw_step",
+    "rnnt_engine_conv_predictor_saved_bytes", "rnnt_engine_conv_predictor_fwd",
+    "rnnt_engine_conv_predictor_bwd", "rnnt_engine_linear_fwd", "rnnt_engine_linear_bwd_workspace_bytes",
+    "rnnt_engine_linear_bwd",
 )
 
 # per-call kernel variants (include/rnnt_engine.h RNNT_VARIANT_*): bit-identical results
@@ -331,6 +334,55 @@ def joint_loss_fwd(enc, pred, W, bias, targets, logit_lens, target_lens, blank, 
             _p(target_lens), B, T, U1, H, V, int(blank), code, _p(costs), _p(ws),
             ctypes.c_size_t(ws.numel()), _stream(dev)))
     return costs
+
+
+def _rows(x):
+    """[.., K] -> a [M, K] view with unit k-stride and a row stride that is a multiple of 4 floats
+    (copying when the caller's layout does not allow 16-byte row loads, e.g. the permuted encoder view)."""
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x.contiguous().view(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    return x2
+
+
+def linear_fwd(x, W, bias):
+    """y = x W^T + b (C ABI rnnt_engine_linear_fwd; reference rnnt/joint.py:26-30)."""
+    dev = _require_cuda(x, W, bias)
+    _require_dtype(torch.float32, x=x, W=W, bias=bias)
+    N, K = W.shape
+    if x.shape[-1] != K or bias.shape != (N,):
+        raise RuntimeError("rnnt_amd.linear: x [..,K], W [N,K], bias [N] expected")
+    x2 = _rows(x)
+    M = x2.shape[0]
+    W, bias = W.contiguous(), bias.contiguous()
+    with torch.cuda.device(dev):
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+        _check(lib().rnnt_engine_linear_fwd(_p(x2), ctypes.c_int64(x2.stride(0)), _p(W), _p(bias), M, K, N,
+                                            _p(y), _stream(dev)))
+    return y.view(*x.shape[:-1], N)
+
+
+def linear_bwd(x, W, dy, need_dx=True):
+    """(dx, dW, db) of linear_fwd (C ABI rnnt_engine_linear_bwd)."""
+    dev = _require_cuda(x, W, dy)
+    _require_dtype(torch.float32, x=x, W=W, dy=dy)
+    N, K = W.shape
+    x2 = _rows(x)
+    M = x2.shape[0]
+    dy2 = dy.reshape(M, N).contiguous()
+    W = W.contiguous()
+    with torch.cuda.device(dev):
+        dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev)
+        dx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_dx else None
+        n = ctypes.c_size_t(0)
+        _check(lib().rnnt_engine_linear_bwd_workspace_bytes(M, K, N, ctypes.byref(n)))
+        ws = workspace(dev, n.value)
+        _check(lib().rnnt_engine_linear_bwd(_p(x2), ctypes.c_int64(x2.stride(0)), _p(W), _p(dy2), M, K, N,
+                                            _p(dx), _p(dW), _p(db), _p(ws), ctypes.c_size_t(ws.numel()),
+                                            _stream(dev)))
+    return (dx.view(x.shape) if need_dx else None), dW, db
 
 
 GREEDY_SCAN_MAX_FRAMES = 128

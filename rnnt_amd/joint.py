@@ -25,11 +25,21 @@ class JointNetwork(torch.nn.Module):
         self.joint_ln = torch.nn.Linear(hidden_features, num_classes)
         self.blank_idx = num_classes - 1
 
+    @staticmethod
+    def _linear(layer, x):
+        # HIP tensors with MFMA-friendly sizes go through the engine's small-GEMM kernels (forward
+        # and backward: rnnt_engine_linear_fwd / _bwd); anything else (CPU
+        # export, odd feature sizes) is torch's own Linear
+        if (x.is_cuda and x.dtype == torch.float32 and layer.in_features % 4 == 0
+                and layer.out_features % 4 == 0 and not torch.jit.is_tracing()):
+            return F_amd.linear(x, layer.weight, layer.bias)
+        return layer(x)
+
     def _project(self, audio_frame, text_frame):
         if hasattr(self, "audio_ln"):
-            audio_frame = self.audio_ln(audio_frame)
+            audio_frame = self._linear(self.audio_ln, audio_frame)
         if hasattr(self, "text_ln"):
-            text_frame = self.text_ln(text_frame)
+            text_frame = self._linear(self.text_ln, text_frame)
         return audio_frame, text_frame
 
     def forward(self, audio_frame, text_frame):

@@ -1,0 +1,112 @@
+"""-m gpu: rnnt_amd.ConvPredictor (C ABI rnnt_engine_conv_predictor_fwd/_bwd) and the engine's Linear
+(rnnt_engine_linear_fwd/_bwd) against the golden vectors produced by the reference's own
+rnnt.predictor.ConvPredictor (tests/golden/predictor_*.npz) and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import predictor_oracle as po
+from tests.helpers import assert_close_grad
+from tests.test_predictor_oracle import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(amd, sd, S, O, E, p=0.3):
+    m = amd.ConvPredictor(S, O, E, dropout=p).cuda()
+    missing = m.load_state_dict({k: torch.from_numpy(np.asarray(v)).float() for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys  # the reference's state-dict keys
+    return m
+
+
+@pytest.mark.parametrize("name", ["predictor_small", "predictor_mid", "predictor_one"])
+def test_conv_predictor_matches_reference_golden(golden_dir, name):
+    import rnnt_amd
+    z, sd, grads = load_case(golden_dir, name)
+    S, O, E, B, U1 = (int(v) for v in z["dims"])
+    m = _module(rnnt_amd, sd, S, O, E).eval()
+    out = m(torch.from_numpy(z["ids"]).cuda())
+    (out * torch.from_numpy(z["G"]).float().cuda()).sum().backward()
+    assert_close_grad("out", out.detach().cpu().numpy(), z["out_f64"], rtol=1e-5, atol=1e-5)
+    got = dict(m.named_parameters())
+    for k in po.PARAMS:
+        assert_close_grad(k, got[k].grad.cpu().numpy(), grads[k])
+
+
+@pytest.mark.parametrize("B,U1,S,E,O,p", [(8, 51, 1024, 512, 1024, 0.3), (3, 70, 33, 36, 20, 0.5), (32, 5, 64, 128, 64, 0.0)])
+def test_conv_predictor_training_mode_vs_oracle(B, U1, S, E, O, p):
+    """Training mode with explicit dropout keep masks (the reference draws them inside nn.Dropout),
+    at the reference's real sizes (E=512, O=1024, S=1024; basic_sp_convjs_fullcausal.yaml:20-25)."""
+    import rnnt_amd
+    torch.manual_seed(B + U1)
+    m = rnnt_amd.ConvPredictor(S, O, E, dropout=p).cuda().train()
+    ids = torch.randint(0, S, (B, U1), device="cuda")
+    k1 = (torch.rand(B, U1, E, device="cuda") >= p).to(torch.uint8)
+    k2 = (torch.rand(B, U1, E, device="cuda") >= p).to(torch.uint8)
+    G = torch.randn(B, U1, O, device="cuda")
+    out = m(ids, keep_masks=(k1, k2))
+    (out * G).sum().backward()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    ref, cache = po.forward(ids.cpu().numpy(), sd, k1.cpu().numpy().astype(np.float64),
+                            k2.cpu().numpy().astype(np.float64), p=p)
+    assert_close_grad("out", out.detach().cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    g = po.backward(G.cpu().numpy(), cache)
+    got = dict(m.named_parameters())
+    for k in po.PARAMS:
+        assert_close_grad(k, got[k].grad.cpu().numpy(), g[k], rtol=2e-4)
+    # masks drawn by the module itself: governed by torch's generator, ~p of the units dropped
+    if p > 0:
+        torch.manual_seed(5); a = m(ids)
+        torch.manual_seed(5); b = m(ids)
+        torch.manual_seed(6); c = m(ids)
+        assert torch.equal(a, b) and not torch.equal(a, c)
+        assert torch.equal(m.eval()(ids), m(ids))  # eval: deterministic
+
+
+def test_conv_predictor_is_deterministic_with_repeated_symbols():
+    """The embedding gradient sums rows in a fixed order (no atomics): bitwise reproducible."""
+    import rnnt_amd
+    torch.manual_seed(0)
+    m = rnnt_amd.ConvPredictor(8, 32, 16, dropout=0.0).cuda()
+    ids = torch.randint(0, 8, (16, 40), device="cuda")  # every symbol ~80 times
+    G = torch.randn(16, 40, 32, device="cuda")
+    gs = []
+    for _ in range(2):
+        m.zero_grad()
+        (m(ids) * G).sum().backward()
+        gs.append([p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(x, y) for x, y in zip(*gs))
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 8, 4), (37, 24, 32), (408, 512, 1024), (2100, 1024, 640), (130, 20, 36)])
+def test_engine_linear_fwd_bwd_vs_torch(M, K, N):
+    import rnnt_amd
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device="cuda", requires_grad=True)
+    G = torch.randn(M, N, device="cuda")
+    y = rnnt_amd.linear(x, W, b)
+    (y * G).sum().backward()
+    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    ref = torch.nn.functional.linear(x64, W64, b64)
+    (ref * G.double()).sum().backward()
+    assert_close_grad("y", y.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5)
+    for name, a_, r_ in (("dx", x, x64), ("dW", W, W64), ("db", b, b64)):
+        assert_close_grad(name, a_.grad.cpu().numpy(), r_.grad.cpu().numpy())
+
+
+def test_engine_linear_on_permuted_encoder_view():
+    """audio_ln applied to the (N,C,L)->(N,L,C) permuted view of reference rnnt/model.py:28."""
+    import rnnt_amd
+    torch.manual_seed(1)
+    enc = torch.randn(3, 24, 50, device="cuda", requires_grad=True)  # (N,C,L)
+    lin = torch.nn.Linear(24, 64).cuda()
+    y = rnnt_amd.linear(enc.permute(0, 2, 1), lin.weight, lin.bias)
+    G = torch.randn_like(y)
+    (y * G).sum().backward()
+    g_eng = enc.grad.clone(); gw = lin.weight.grad.clone()
+    enc.grad = None; lin.zero_grad()
+    (lin(enc.permute(0, 2, 1)) * G).sum().backward()
+    assert torch.allclose(y, lin(enc.permute(0, 2, 1)), atol=1e-5)
+    assert torch.allclose(enc.grad, g_eng, atol=1e-4) and torch.allclose(lin.weight.grad, gw, atol=1e-4)
