@@ -400,6 +400,12 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int Tb = WITH_LOSS ? len_t(a.logit_lens, b, a.T) : T;
     const int ncell = Tb * U1;
+    // Two workgroups share every SIMD of the CU.  A wave in one of its short non-MFMA phases (hidden
+    // production, pass epilogue, finalisation) issues at priority 1, a wave in its main loop at 0: the
+    // partner's MFMA stream needs one issue slot per 64 cycles and is not slowed, while the phase that
+    // used to wait behind it (the SIMD arbitrates oldest-first at equal priority) overlaps it
+    // (cfg2: 51.1 -> 50.3 ms).
+    __builtin_amdgcn_s_setprio(1);
     if (MAKE_HID) {
         // hidden = tanh(enc + pred) for this tile's cells, produced here instead of by a separate
         // 13 GB pass (k_make_hidden): ~1 % of the tile's time, and the main loop's loads of it hit
@@ -522,8 +528,10 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
         const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
         const int gvalid = min(4, NG - pass * 4);
         STAMP(1 + 2 * (pass & 1));
+        __builtin_amdgcn_s_setprio(0);
         fwd_mainloop<USE_HID, PAIRS, BREG>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
                                 s_b, acc);
+        __builtin_amdgcn_s_setprio(1);
         STAMP(2 + 2 * (pass & 1));
 
         // ---- epilogue: store logits, fold this pass into the running row log-sum-exp
