@@ -303,14 +303,15 @@ def main():
         # profile committed for this config (profiles/r01_traffic.json), else null
         try:
             key = args.config if args.dtype == "fp32" else args.config + "_bf16"
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[key][dom]
+            tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))[-1]
+            tr = json.load(open(os.path.join(ROOT, "profiles", tfile)))[key][dom]
             if world == 1:
                 # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane
                 # streams (every load of these kernels is 16 B/lane) -> doubled; WRITE_SIZE is exact
                 out["roofline"]["traffic"] = 2 * tr["fetch_raw"] + tr["write"]
                 out["roofline"]["traffic_note"] = ("bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 PMC, separate "
                                                    "passes, KB x 1024; gfx950 half-count correction for 16 B/lane loads), "
-                                                   "profiles/r01_traffic.json; algorithmic HBM bytes %.3g" % tr["algorithmic"])
+                                                   "profiles/%s; algorithmic HBM bytes %.3g" % (tfile, tr["algorithmic"]))
         except Exception:  # noqa: BLE001
             pass
         sweep_bytes = 24.0 * cells1

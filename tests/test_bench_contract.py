@@ -31,16 +31,26 @@ def _check(d, dtype):
     assert c["kind"] in ("port", "reference") and c["unit"] == "cells/s" and c["cores"] >= 1
 
 
-def test_committed_fp32_bench_line():
-    d = _line("r01_bench_default.json")
+import pytest
+
+
+@pytest.mark.parametrize("rnd", ["r01", "r02"])
+def test_committed_fp32_bench_line(rnd):
+    d = _line(f"{rnd}_bench_default.json")
     _check(d, "f32")
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 157.3
+    if rnd != "r01":
+        assert d["roofline"]["traffic"] > 0 and d["hipGetDeviceCount"] >= 1 and d["rccl_ranks"] == 0
+        assert "median of 3 runs" in d["cpu_baseline"]["sample"]
 
 
-def test_committed_bf16_bench_line():
-    d = _line("r01_bf16_bench_default.json")
+@pytest.mark.parametrize("rnd", ["r01", "r02"])
+def test_committed_bf16_bench_line(rnd):
+    d = _line(f"{rnd}_bf16_bench_default.json")
     _check(d, "bf16")
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    if rnd != "r01":
+        assert d["steps"] == 20
 
 
 def test_bench_refuses_to_run_fewer_gpus_than_asked():

@@ -70,3 +70,30 @@ for key, (dt, ks) in names.items():
         out[key][stage] = {"fetch_raw": int(fr * 1024), "write": int(wr * 1024), "algorithmic": int(alg[key][stage])}
 json.dump(out, open(os.path.join(dst, f"{rnd}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# ---- SQ counters of the shipped fp32 kernels + the MFMA utilisation they imply
+sq_path = os.path.join(src, f"{tag}.fp32.SQ.txt")
+if os.path.exists(sq_path):
+    blocks, cur = {}, None
+    for line in open(sq_path):
+        if not line.startswith(" "):
+            cur = line.strip(); blocks[cur] = {}
+        else:
+            parts = line.split()
+            blocks[cur][parts[0]] = float(parts[1])
+    with open(os.path.join(dst, f"{rnd}_sq_counters_pmc.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE (one pass, 8 SQ slots), `python3 bench.py --steps 1 --warmup 1`, cfg2 fp32,\n"
+                "# means over the full-size launches of each SHIPPED kernel.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES /\n"
+                "# (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): fraction of the chip's matrix-pipe cycles that carried an MFMA.\n")
+        for k, c in blocks.items():
+            if not any(x in k for x in ("k_joint_fwd_persist", "k_dhidden_gen", "k_dw")) or "table" in k:
+                continue
+            f.write(k + "\n")
+            for n, v in sorted(c.items()):
+                f.write(f"   {n:32s} {v:.4g}\n")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+                f.write(f"   {'mfma_util':32s} {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.4f}\n")
+    print(open(os.path.join(dst, f"{rnd}_sq_counters_pmc.txt")).read())
+for extra in ("ref1024.json", "cfg4.json", "ref1024.kernel_stats.csv", "ref1024.bf16.json"):
+    if os.path.exists(os.path.join(src, f"{tag}.{extra}")):
+        cp(f"{tag}.{extra}", f"{rnd}_{extra.replace(".bf16", "_bf16").replace(".json", "_bench.json").replace('.kernel_stats.csv', '_kernel_stats.csv')}")
