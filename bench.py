@@ -36,6 +36,9 @@ CONFIGS = {
     # BASELINE config 1's plumbing shape and a training-sized batch of it
     "cfg1": (2, 208, 50, 1024, 1024),
     "ref1024": (8, 500, 100, 1024, 1024),
+    "ref512": (8, 500, 100, 512, 1024),     # the same lattice at H = 512: like-for-like with ref1024
+    "ref1024b": (32, 500, 103, 1024, 1024),  # U1 = 104: no dead rows in 8- or 16-wide u tiles
+    "ref512b": (32, 500, 103, 512, 1024),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0

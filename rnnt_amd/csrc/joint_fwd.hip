@@ -5,22 +5,28 @@
 //   logits[b,t,u,:] = tanh(enc[b,t,:] + pred[b,u,:]) @ W^T + bias          (materialised)
 //   denom = logsumexp_v logits ; lp_blank = logits[blank]-denom ; lp_emit = logits[y_u]-denom
 //
-// Design (MI355X-first, fp32 exact):
-//  * GEMM M = lattice cells (128 per workgroup, linear cell index inside one utterance),
-//    K = H, N = V.  v_mfma_f32_32x32x2_f32 takes ONE f32 VGPR per operand and occupies the
-//    matrix pipe for 64 cycles, so operands go straight from L2/HBM to registers — no LDS
-//    staging, no barriers in the main loop; LDS only carries the per-row softmax state.
-//  * The A operand (hidden) is never stored: each lane loads 16 B of enc and pred for its
-//    row and applies tanh in registers.  A lane's 4 consecutive k feed 4 MFMAs because the
-//    k-order inside an 8-wide chunk is a free permutation: lanes 0-31 take k0..k0+3, lanes
-//    32-63 take k0+4..k0+7 for both A and B.
-//  * W is re-packed once per call (pack_w_fwd) so that a B fragment is one lane-linear
-//    1 KiB load; columns are interleaved by 4 (tile q of a 128-column group holds columns
-//    4j+q) so that a lane's accumulators for q=0..3 are 4 consecutive logits -> 16-byte
-//    coalesced stores (512 contiguous bytes per half-wave).
-//  * 8 waves = 4(M) x 2(N); each wave owns a 32 x 256 tile (8 accumulator tiles, 128 VGPRs)
-//    and the workgroup walks V in passes of 512 columns keeping a running (max, sum) per
-//    row, so the row's log-sum-exp is complete when the last pass ends.
+// Design (MI355X-first, fp32 exact; DESIGN.md §4):
+//  * GEMM M = lattice cells (64 per tile, linear cell index inside one utterance), K = H, N = V.
+//    v_mfma_f32_32x32x2_f32 takes ONE f32 VGPR per operand and occupies the matrix pipe for 64
+//    cycles, so operands go straight from L2 to registers — no LDS staging and no barrier in the
+//    default main loop; LDS only carries the per-row softmax state.
+//  * hidden = tanh(enc + pred) is produced ONCE, by the tile's own prologue (wave = rows, lane = 4 h),
+//    stored to the workspace (both backward GEMMs read it again) and read back from L2 as the A
+//    operand: a lane's 16-byte load supplies 4 k-steps because the k order inside an 8-wide chunk is
+//    a free permutation (lanes 0-31 take k0..k0+3, lanes 32-63 take k0+4..k0+7, for A and B alike).
+//    The plain joint (rnnt_engine_joint_fwd, no workspace for hidden) computes tanh in the loop.
+//  * W is re-packed once per call (k_pack_w_fwd) into MFMA-fragment order: a B fragment is one
+//    lane-linear 1 KiB load; columns are interleaved by 4 (tile q of a 128-column group holds columns
+//    4j+q) so that a lane's accumulators for q = 0..3 are 4 consecutive logits -> 16-byte stores.
+//  * 4 waves = 2 (M) x 2 (N), one per SIMD; each wave owns a 32 x 256 tile (8 accumulator tiles, 128
+//    registers), so TWO workgroups share a CU; the workgroup walks V in passes of 512 columns keeping
+//    a per-lane running (max, sum) per row in LDS — the row's log-sum-exp is complete when the last
+//    pass ends.  Default main loop (BREG): A slices and B fragments stream into two register sets that
+//    alternate by chunk parity, read by the MFMAs directly, one counted vmcnt per chunk.  The LDS-DMA
+//    ring form is kept for odd chunk counts / the plain joint and as a per-call variant
+//    (RNNT_VARIANT_FWD_LDS_RING).
+//  * Persistent launch: 2 workgroups per CU for the whole kernel, tiles from one atomic counter; the
+//    non-MFMA phases of a tile issue at s_setprio 1 so they overlap the co-resident workgroup's MFMAs.
 #include "common.hpp"
 #include "kernels.hpp"
 
