@@ -21,7 +21,7 @@ inline size_t al(size_t x) { return (x + 63) & ~(size_t)63; }  // in floats
 
 struct PredLayout {
     size_t wp1, wp2, x1, st1, y1, g1, y2, g2, z, st2;      // forward (kept for backward)
-    size_t dz, t, dg, dyp, dwp, cs;                        // backward scratch
+    size_t dz, t, dg, dyp, dwp, slabs, cs;                 // backward scratch
     size_t total;
 };
 PredLayout pred_layout(int B, int U1, int E, int O)
@@ -45,6 +45,7 @@ PredLayout pred_layout(int B, int U1, int E, int O)
     L.dg = o;  o += al(M * E);
     L.dyp = o; o += al(M * E);
     L.dwp = o; o += al(5 * (size_t)E * E);
+    L.slabs = o; o += al((size_t)sgemm_tn_splits((int)M) * (5 * (size_t)E * E > (size_t)O * E ? 5 * (size_t)E * E : (size_t)O * E));
     L.cs = o;  o += al(colsum_scratch_floats((int)M, (int)W));
     L.total = o;
     return L;
@@ -144,18 +145,50 @@ __global__ __launch_bounds__(256) void k_gelu_bwd(const float *__restrict__ dG, 
 }
 
 // dEmb[s,:] = sum over the rows m (ascending) with ids[m] == s of dX0[m,:]: deterministic, no atomics
+// One workgroup per symbol: pass 1 lists the rows that carry it, in ascending order (256 rows per
+// step, ballot + prefix counts); pass 2 adds them up in that order.
 __global__ __launch_bounds__(256) void k_embed_bwd(const int64_t *__restrict__ ids, const float *__restrict__ dX0,
                                                    int M, int E, int S, float *__restrict__ dEmb)
 {
-    const int s = blockIdx.x;
-    for (int e0 = threadIdx.x * 4; e0 < E; e0 += 1024) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int m = 0; m < M; ++m) {
-            long id = ids[m];  // block-uniform
-            id = id < 0 ? 0 : (id >= S ? S - 1 : id);
-            if (id == s) acc += *(const f32x4 *)(dX0 + (long)m * E + e0);
+    constexpr int CAP = 2048;  // rows listed per round
+    __shared__ int s_list[CAP];
+    __shared__ int s_cnt[5];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // E <= 2048 in two column sweeps of 1024
+    const int sweeps = (E + 1023) / 1024;
+    for (int base = 0; base < M;) {
+        int n = 0;  // rows listed so far this round (block-uniform)
+        int m0 = base;
+        for (; m0 < M && n + 256 <= CAP; m0 += 256) {
+            const int m = m0 + tid;
+            bool hit = false;
+            if (m < M) {
+                long id = ids[m];
+                id = id < 0 ? 0 : (id >= S ? S - 1 : id);
+                hit = id == s;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) s_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = n;
+            for (int w = 0; w < wave; ++w) off += s_cnt[w];
+            if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = m;
+            n += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            __syncthreads();
         }
-        *(f32x4 *)(dEmb + (long)s * E + e0) = acc;
+        base = m0;
+        for (int k = 0; k < n; ++k) {
+            const float *row = dX0 + (long)s_list[k] * E;
+            for (int sw = 0; sw < sweeps && sw < 2; ++sw) {
+                const int e0 = sw * 1024 + tid * 4;
+                if (e0 < E) acc[sw] += *(const f32x4 *)(row + e0);
+            }
+        }
+        __syncthreads();
+    }
+    for (int sw = 0; sw < sweeps && sw < 2; ++sw) {
+        const int e0 = sw * 1024 + tid * 4;
+        if (e0 < E) *(f32x4 *)(dEmb + (long)s * E + e0) = acc[sw];
     }
 }
 
@@ -163,8 +196,8 @@ int check_pred_dims(int B, int U1, int S, int E, int O)
 {
     if (B <= 0 || U1 <= 0 || S <= 0 || E <= 0 || O <= 0)
         return engine_fail(RNNT_ERR_INVALID_ARG, "non-positive dimension B=%d U1=%d S=%d E=%d O=%d", B, U1, S, E, O);
-    if (E % 4 != 0 || O % 4 != 0)
-        return engine_fail(RNNT_ERR_UNSUPPORTED, "ConvPredictor kernels need E %% 4 == 0 and O %% 4 == 0 (E=%d O=%d)", E, O);
+    if (E % 4 != 0 || O % 4 != 0 || E > 2048)
+        return engine_fail(RNNT_ERR_UNSUPPORTED, "ConvPredictor kernels need E %% 4 == 0, E <= 2048 and O %% 4 == 0 (E=%d O=%d)", E, O);
     if ((long)B * U1 > 0x3fffffffL) return engine_fail(RNNT_ERR_UNSUPPORTED, "B*U1 too large");
     return RNNT_OK;
 }
@@ -181,7 +214,7 @@ SgArgs sg(const float *A, long lda, const float *B, long ldb, float *C, long ldc
     SgArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
     a.bias = nullptr; a.Cpre = nullptr; a.mask = nullptr; a.mask_scale = 1.f;
-    a.M = M; a.N = N; a.K = K; a.taps = taps; a.seg = seg; a.act = 0;
+    a.M = M; a.N = N; a.K = K; a.taps = taps; a.seg = seg; a.act = 0; a.ksplit = 1;
     return a;
 }
 
@@ -268,20 +301,26 @@ int rnnt_engine_conv_predictor_bwd(const int64_t *ids, int B, int U1, int S, int
     launch_colsum(ws + L.t, O, M, O, gp[9], cs, st);
     launch_colsum(grad_out, O, M, O, gp[10], cs, st);
     // linear: dW = dz^T g2, db = colsum(dz), dg2 = dz W
-    launch_sgemm_tn(sg(ws + L.dz, O, ws + L.g2, E, gp[7], E, M, O, E, 1, M), st);
+    const int KS = sgemm_tn_splits(M);
+    auto wgrad = [&](SgArgs a, float *out) {  // contraction split over KS workgroups, slabs summed in order
+        a.ksplit = KS; a.C = ws + L.slabs;
+        launch_sgemm_tn(a, st);
+        launch_sum_slabs(ws + L.slabs, out, (long)a.taps * a.N * a.K, KS, st);
+    };
+    wgrad(sg(ws + L.dz, O, ws + L.g2, E, nullptr, E, M, O, E, 1, M), gp[7]);
     launch_colsum(ws + L.dz, O, M, O, gp[8], cs, st);
     launch_sgemm_nn(sg(ws + L.dz, O, p->linear_w, E, ws + L.dg, E, M, E, O, 1, M), st);
     // conv2: through dropout + gelu, then dWp2 / db2 / dg1
     hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)(((long)M * E + 255) / 256)), dim3(256), 0, st, ws + L.dg,
                        ws + L.y2, keep2, scale, (long)M * E, ws + L.dyp);
-    launch_sgemm_tn(sg(ws + L.dyp, E, ws + L.g1, E, ws + L.dwp, E, M, E, E, 5, U1), st);
+    wgrad(sg(ws + L.dyp, E, ws + L.g1, E, nullptr, E, M, E, E, 5, U1), ws + L.dwp);
     launch_unpack_conv_w(ws + L.dwp, gp[5], E, E, 5, st);
     launch_colsum(ws + L.dyp, E, M, E, gp[6], cs, st);
     launch_sgemm_nn(sg(ws + L.dyp, E, ws + L.wp2, E, ws + L.dg, E, M, E, E, 5, U1), st);
     // conv1
     hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)(((long)M * E + 255) / 256)), dim3(256), 0, st, ws + L.dg,
                        ws + L.y1, keep1, scale, (long)M * E, ws + L.dyp);
-    launch_sgemm_tn(sg(ws + L.dyp, E, ws + L.x1, E, ws + L.dwp, E, M, E, E, 3, U1), st);
+    wgrad(sg(ws + L.dyp, E, ws + L.x1, E, nullptr, E, M, E, E, 3, U1), ws + L.dwp);
     launch_unpack_conv_w(ws + L.dwp, gp[3], E, E, 3, st);
     launch_colsum(ws + L.dyp, E, M, E, gp[4], cs, st);
     launch_sgemm_nn(sg(ws + L.dyp, E, ws + L.wp1, E, ws + L.dg, E, M, E, E, 3, U1), st);
@@ -313,7 +352,7 @@ int rnnt_engine_linear_bwd_workspace_bytes(int M, int K, int N, size_t *out)
 {
     if (!out) return engine_fail(RNNT_ERR_INVALID_ARG, "null size pointer");
     if (M <= 0 || K <= 0 || N <= 0) return engine_fail(RNNT_ERR_INVALID_ARG, "non-positive dimension");
-    *out = colsum_scratch_floats(M, N) * 4 + 256;
+    *out = (colsum_scratch_floats(M, N) + 64 + (size_t)sgemm_tn_splits(M) * N * K) * 4 + 256;
     return RNNT_OK;
 }
 
@@ -331,7 +370,13 @@ int rnnt_engine_linear_bwd(const float *x, int64_t ldx, const float *W, const fl
     if ((dx && ((uintptr_t)dx & 15)) || (db && ((uintptr_t)db & 15))) return engine_fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned");
     if (ws_bytes < need) return engine_fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    launch_sgemm_tn(sg(dy, N, x, ldx, dW, K, M, N, K, 1, M), st);
+    {
+        float *slabs = (float *)workspace + ((colsum_scratch_floats(M, N) + 63) & ~(size_t)63);
+        SgArgs a = sg(dy, N, x, ldx, slabs, K, M, N, K, 1, M);
+        a.ksplit = sgemm_tn_splits(M);
+        launch_sgemm_tn(a, st);
+        launch_sum_slabs(slabs, dW, (long)N * K, a.ksplit, st);
+    }
     if (db) launch_colsum(dy, N, M, N, db, (float *)workspace, st);
     if (dx) launch_sgemm_nn(sg(dy, N, W, K, dx, K, M, K, N, 1, M), st);
     return status("rnnt_engine_linear_bwd");

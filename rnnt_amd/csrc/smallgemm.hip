@@ -166,11 +166,15 @@ __global__ __launch_bounds__(256, 1) void k_sgemm_tn(SgArgs a)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, half = lane >> 5;
     const int Mc = a.M, N = a.N, K = a.K;
-    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128, tap = blockIdx.z;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int ks_n = a.ksplit > 0 ? a.ksplit : 1;
+    const int tap = blockIdx.z / ks_n, split = blockIdx.z - tap * ks_n;
     const bool nok = n0 + 4 * i < N, kok = k0 + 4 * i < K;
     const int ncol = nok ? n0 + 4 * i : N - 4, kcol = kok ? k0 + 4 * i : K - 4;
     const int shift = tap - (a.taps - 1);
-    const int steps = (Mc + 1) / 2;
+    const int steps_all = (Mc + 1) / 2;
+    const int s_lo = (int)((long)steps_all * split / ks_n), s_hi = (int)((long)steps_all * (split + 1) / ks_n);
+    const int steps = s_hi - s_lo;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void k_sgemm_tn(SgArgs a)
 
     struct Ops { f32x4 y, x; };
     auto load = [&](Ops &o, int ks) {
-        const int m = 2 * ks + half;
+        const int m = 2 * (s_lo + ks) + half;
         const bool mok = m < Mc;
         const int mm = mok ? m : Mc - 1;
         const bool xok = mok && (mm % a.seg) + shift >= 0;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void k_sgemm_tn(SgArgs a)
             const int n = n0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * half) + qm;
             if (n >= N) continue;
             const f32x4 o = {acc[qm][0][r], acc[qm][1][r], acc[qm][2][r], acc[qm][3][r]};
-            *(f32x4 *)(a.C + ((long)tap * N + n) * a.ldc + kcol) = o;
+            *(f32x4 *)(a.C + (((long)split * a.taps + tap) * N + n) * a.ldc + kcol) = o;
         }
 }
 
@@ -256,6 +260,16 @@ __global__ __launch_bounds__(256) void k_colsum2(const float *__restrict__ scrat
     out[n] = s;
 }
 
+__global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, float *__restrict__ out,
+                                                   long n4, int ns)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    f32x4 s = ((const f32x4 *)slabs)[idx];
+    for (int k = 1; k < ns; ++k) s += ((const f32x4 *)slabs)[(long)k * n4 + idx];
+    ((f32x4 *)out)[idx] = s;
+}
+
 }  // namespace
 
 void launch_sgemm_nt(const SgArgs &a, hipStream_t st)
@@ -268,7 +282,14 @@ void launch_sgemm_nn(const SgArgs &a, hipStream_t st)
 }
 void launch_sgemm_tn(const SgArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sgemm_tn, dim3((a.K + 127) / 128, (a.N + 127) / 128, a.taps), dim3(256), 0, st, a);
+    const int ks = a.ksplit > 0 ? a.ksplit : 1;
+    hipLaunchKernelGGL(k_sgemm_tn, dim3((a.K + 127) / 128, (a.N + 127) / 128, a.taps * ks), dim3(256), 0, st, a);
+}
+// one range per ~256 contraction rows, at most 16: a few hundred MFMA k-steps per wave
+int sgemm_tn_splits(int Mc) { const int s = (Mc + 255) / 256; return s < 1 ? 1 : (s > 16 ? 16 : s); }
+void launch_sum_slabs(const float *slabs, float *out, long n, int ns, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slabs, out, n / 4, ns);
 }
 void launch_pack_conv_w(const float *w, float *wp, int out_c, int in_c, int taps, hipStream_t st)
 {

@@ -28,11 +28,16 @@ struct SgArgs {
                                 // per tap (Kc); TN: contraction rows (Mc), output rows N, cols K
     int taps, seg;              // conv taps (1: plain GEMM), rows per sequence
     int act;                    // NT: 0 none, 1 exact GELU (torch.nn.functional.gelu default)
+    int ksplit;                 // TN: the contraction rows are cut into `ksplit` ranges, one workgroup each,
+                                // partial results in C[split][taps][N][K] (launch_sum_slabs adds them up)
 };
 
 void launch_sgemm_nt(const SgArgs &a, hipStream_t st);
 void launch_sgemm_nn(const SgArgs &a, hipStream_t st);  // conv: shift(tap) = (taps-1) - tap (transposed conv)
 void launch_sgemm_tn(const SgArgs &a, hipStream_t st);
+int sgemm_tn_splits(int Mc);  // how many ranges launch_sgemm_tn callers should ask for
+// out[i] = sum_s slabs[s][i], i < n (n % 4 == 0), fixed order
+void launch_sum_slabs(const float *slabs, float *out, long n, int ns, hipStream_t st);
 // conv weight [out][in][tap] (torch Conv1d) -> [tap][out][in]; and back (gradient)
 void launch_pack_conv_w(const float *w, float *wp, int out_c, int in_c, int taps, hipStream_t st);
 void launch_unpack_conv_w(const float *wp, float *w, int out_c, int in_c, int taps, hipStream_t st);
