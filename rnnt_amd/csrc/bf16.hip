@@ -4,7 +4,7 @@
 // rnnt/model.py:35-41 + their autograd), but the operands of the three GEMMs are rounded to
 // bf16 (round-to-nearest-even) and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation — 16x the fp32 matrix rate, so this route is HBM-bound:
-//   hidden = bf16(tanh(enc+pred))        k_make_hidden_bf16      writes  2H  B/cell
+//   hidden = bf16(tanh(enc+pred))        forward-tile prologue   writes  2H  B/cell
 //   logits = f16(hidden . bf16(W)^T + b) k_joint_fwd_bf16        reads 2H, writes 2V B/cell
 //   softmax statistics, lattice, coef    fp32 / fp64, shared with the fp32 route (lattice.hip)
 //   G = bf16(exp2(logit*log2e+c1) - ..)  k_dhidden_bf16          reads 2V+2H, writes 2V B/cell
@@ -69,51 +69,37 @@ __device__ __forceinline__ void lds_barrier()
 // ---------------------------------------------------------------------------------------
 // producers
 // ---------------------------------------------------------------------------------------
-// hidden[c,:] = bf16(tanh(enc[b,t,:] + pred[b,u,:])), zero rows for c >= cells (row padding).
-// A thread owns 8 columns (16 B of bf16) of HID_R consecutive cells: they share their enc row
-// unless the run crosses a t boundary, so the kernel issues ~2.5 loads per 16-byte store
-// instead of 4 (it is bound by load/store issue, not by HBM: 6.6 GB written).
-#define HID_R 4
-__global__ __launch_bounds__(256) void k_make_hidden_bf16(const float *__restrict__ enc, long sb,
-                                                          long st_, const float *__restrict__ pred,
-                                                          u32x4 *__restrict__ hid, int B, int T,
-                                                          int U1, int H, long rows)
+// hidden[c,:] = bf16(tanh(enc[b,t,:] + pred[b,u,:])) for the 128 cells of one forward tile, produced
+// by the tile's own workgroup (the separate 6.6 GB producer pass of round 1, 1.6 ms at cfg2, is
+// gone: its loads, tanh and stores now run beside the co-resident workgroup's main loop).  A thread
+// owns 8 columns (16 B of bf16) of every (256 / (H/8))-th row; (b,t,u) is carried along, no division
+// inside the loop.  EVERY cell of the tile gets a finite row, also past its utterance's length: the
+// backward GEMMs multiply those rows by exact zeros.  Rows past the last cell are zeroed by the host.
+__device__ __forceinline__ void make_hidden_tile_bf16(const Bf16Args &a, long c_first, int tid)
 {
-    const int H8 = H / 8;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long grp = idx / H8;  // run of HID_R cells
-    const int h = (int)(idx - grp * H8) * 8;
-    const long c0 = grp * HID_R;
-    if (c0 >= rows) return;
-    const long cells = (long)B * T * U1;
-    int u = (int)(c0 % U1);
-    const long bt0 = c0 / U1;
-    int t = (int)(bt0 % T), b = (int)(bt0 / T);  // carried along the run: no further divisions
-    f32x4 e0, e1;
-    bool have_e = false;
-#pragma unroll
-    for (int i = 0; i < HID_R; ++i) {
-        const long c = c0 + i;
-        if (c >= rows) break;
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (c < cells) {
-            if (!have_e) {
-                const float *ep = enc + (long)b * sb + (long)t * st_ + h;
-                e0 = *(const f32x4 *)ep; e1 = *(const f32x4 *)(ep + 4);
-                have_e = true;
-            }
-            const float *pp = pred + ((long)b * U1 + u) * H + h;
-            const f32x4 p0 = *(const f32x4 *)pp, p1 = *(const f32x4 *)(pp + 4);
-            o[0] = pack_bf16(fast_tanh(e0[0] + p0[0]), fast_tanh(e0[1] + p0[1]));
-            o[1] = pack_bf16(fast_tanh(e0[2] + p0[2]), fast_tanh(e0[3] + p0[3]));
-            o[2] = pack_bf16(fast_tanh(e1[0] + p1[0]), fast_tanh(e1[1] + p1[1]));
-            o[3] = pack_bf16(fast_tanh(e1[2] + p1[2]), fast_tanh(e1[3] + p1[3]));
-        }
+    const int H = a.H, H8 = H / 8, U1 = a.U1, T = a.T;
+    const long cells = (long)a.B * T * U1;
+    const int rstep = 256 / H8 > 0 ? 256 / H8 : 1;      // rows per sweep (H <= 2048)
+    const int r0 = tid / H8, h = (tid - r0 * H8) * 8;
+    if (r0 >= rstep) return;                             // H8 not a divisor of 256: idle threads
+    long c = c_first + r0;
+    int u = (int)(c % U1);
+    long bt = c / U1;
+    int t = (int)(bt % T), b = (int)(bt / T);
+    u32x4 *hid = (u32x4 *)a.hidden;
+    for (int r = r0; r < 128 && c < cells; r += rstep, c += rstep) {
+        const float *ep = a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + h;
+        const float *pp = a.pred + ((long)b * U1 + u) * H + h;
+        const f32x4 e0 = *(const f32x4 *)ep, e1 = *(const f32x4 *)(ep + 4);
+        const f32x4 p0 = *(const f32x4 *)pp, p1 = *(const f32x4 *)(pp + 4);
+        u32x4 o;
+        o[0] = pack_bf16(fast_tanh(e0[0] + p0[0]), fast_tanh(e0[1] + p0[1]));
+        o[1] = pack_bf16(fast_tanh(e0[2] + p0[2]), fast_tanh(e0[3] + p0[3]));
+        o[2] = pack_bf16(fast_tanh(e1[0] + p1[0]), fast_tanh(e1[1] + p1[1]));
+        o[3] = pack_bf16(fast_tanh(e1[2] + p1[2]), fast_tanh(e1[3] + p1[3]));
         hid[c * H8 + h / 8] = o;
-        if (++u == U1) {  // next cell starts a new enc row
-            u = 0; have_e = false;
-            if (++t == T) { t = 0; ++b; }
-        }
+        u += rstep;
+        while (u >= U1) { u -= U1; if (++t == T) { t = 0; ++b; } }
     }
 }
 
@@ -168,10 +154,10 @@ size_t bf16_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V
 
 void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
 {
-    const long nh = (a.rows_alloc + HID_R - 1) / HID_R * (a.H / 8);
-    hipLaunchKernelGGL(k_make_hidden_bf16, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, st,
-                       a.enc, a.enc_sb, a.enc_st, a.pred, (u32x4 *)a.hidden, a.B, a.T, a.U1, a.H,
-                       a.rows_alloc);
+    // hidden is produced by the forward kernel's tiles; only the zero padding rows past the last cell
+    // (the dW DMA ring walks them) are written here
+    const long cells = (long)a.B * a.T * a.U1;
+    (void)hipMemsetAsync(a.hidden + cells * a.H, 0, (size_t)(a.rows_alloc - cells) * a.H * 2, st);
     const long nf = (long)(bf16_wpack_fwd_bytes(a.H, a.V) / 16);
     hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W,
                        (u32x4 *)a.wpack_fwd, a.H, a.V, a.H / 32, nf);
@@ -255,10 +241,12 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
         const long cells = (long)a.B * a.T * a.U1, per = (long)a.T * a.U1;
         const long c_first = (long)blockIdx.x * 128, c_last = c_first + 127;
         if (c_first >= cells) return;
+        make_hidden_tile_bf16(a, c_first, tid);  // also for dead tiles: hidden must be finite everywhere
         const long b_first = c_first / per;
         if (c_last < cells && c_last / per == b_first &&
             (c_first - b_first * per) / a.U1 >= len_t(a.logit_lens, b_first, a.T)) return;
     }
+    __syncthreads();  // the tile's hidden rows are stored (vmcnt(0)) and every wave is past them
     const long row0 = (long)blockIdx.x * 128 + wave * 32;
     const u32x4 *ap = (const u32x4 *)(a.hidden + (row0 + j) * H) + 2 * half;  // chunk c: ap[4c], ap[4c+1]
     const u32x4 *wp = (const u32x4 *)a.wpack_fwd;
