@@ -110,7 +110,10 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
     L->slab_w = o;   o += align_up((size_t)L->n_split * V * H * 4);
     L->slab_b = o;   o += align_up((size_t)L->n_split * V * 4);
-    L->counters = o; o += 1024 + align_up((2 * (size_t)B + 2) * 8);  // + the dW live-row table
+    {   // + the dW live-row table (bf16 route) / live-granule list (fp32 route), whichever is larger
+        const size_t tab = (2 * (size_t)B + 2) * 8, lst = dtype == RNNT_DTYPE_BF16 ? 0 : dw_list_bytes(B, T, U1, 16);
+        L->counters = o; o += 1024 + align_up(tab > lst ? tab : lst);
+    }
     L->total = o;
 }
 

@@ -814,12 +814,120 @@ void launch_dw_table(const int32_t *logit_lens, int B, int T, int U1, int gran, 
     hipLaunchKernelGGL(k_dw_table, dim3(1), dim3(64), 0, st, logit_lens, B, T, U1, gran, tab);
 }
 
+// Live-GRANULE list of the fp32 dW GEMM: list[i] = index of the i-th 16-row granule of the [cells]
+// buffers that holds at least one lattice cell (t < T_b and u <= U_b), ascending; head[0] = their
+// number.  A ragged batch then costs its live CELLS, not its live time steps: the cells with
+// u > U_b of every live time step (a quarter of the rows when U_b is uniform in [U/2, U]) drop out
+// of the K walk, apart from the few that share a granule with a live cell (k_dhidden_gen / k_make_g
+// write exact zeros there).  Built by three small launches (flags + per-block counts, scan of the
+// block counts, compaction): the order is ascending, so dW stays bitwise reproducible.
+__device__ __forceinline__ bool granule_live(long g, int gran, const int32_t *logit_lens,
+                                             const int32_t *target_lens, int B, int T, int U1)
+{
+    const long cells = (long)B * T * U1;
+    long c = g * gran;
+    if (c >= cells) return false;
+    long bt = c / U1;
+    int u = (int)(c - bt * U1);
+    int t = (int)(bt % T), b = (int)(bt / T);
+    int left = gran;
+    while (left > 0 && b < B) {  // the rows (b,t) this granule touches: first from u, then from 0
+        if (t < len_t(logit_lens, b, T) && u <= len_u(target_lens, b, U1)) return true;
+        left -= U1 - u;
+        u = 0;
+        if (++t == T) { t = 0; ++b; }
+    }
+    return false;
+}
+#define DWL_BLK 1024
+__global__ __launch_bounds__(DWL_BLK) void k_dw_list_count(const int32_t *__restrict__ logit_lens,
+                                                           const int32_t *__restrict__ target_lens, int B, int T,
+                                                           int U1, int gran, long n_gran, int *__restrict__ blk)
+{
+    const long g = (long)blockIdx.x * DWL_BLK + threadIdx.x;
+    const bool live = g < n_gran && granule_live(g, gran, logit_lens, target_lens, B, T, U1);
+    const int cnt = __syncthreads_count(live);
+    if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
+}
+// exclusive scan of the block counts in place (one workgroup); head[0] = total, head[1] = 1 when the
+// list is shorter than the table's live ranges (some granule of a live time step is dead): list walk
+__global__ __launch_bounds__(1024) void k_dw_list_scan(int *__restrict__ blk, int nblk, long *__restrict__ head,
+                                                       const long *__restrict__ tab, int B)
+{
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? blk[i] : 0;
+        int x = v;  // inclusive scan inside the wave, then across the 16 waves
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if ((threadIdx.x & 63) >= d) x += y; }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += s_w[w];
+        if (i < nblk) blk[i] = off + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { head[0] = s_carry; head[1] = s_carry < tab[2 * B + 1] ? 1 : 0; }
+}
+__global__ __launch_bounds__(DWL_BLK) void k_dw_list_write(const int32_t *__restrict__ logit_lens,
+                                                           const int32_t *__restrict__ target_lens, int B, int T,
+                                                           int U1, int gran, long n_gran, const int *__restrict__ blk,
+                                                           int *__restrict__ list)
+{
+    __shared__ int s_w[DWL_BLK / 64];
+    const long g = (long)blockIdx.x * DWL_BLK + threadIdx.x;
+    const bool live = g < n_gran && granule_live(g, gran, logit_lens, target_lens, B, T, U1);
+    const unsigned long long bal = __ballot(live);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int off = blk[blockIdx.x];
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    if (live) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)g;
+}
+
+// region: [0] head (live count, mode) 64 B | table (2B+2 longs) | block offsets | list
+static size_t dwl_tab_bytes(int B) { return (((size_t)2 * B + 2) * 8 + 63) & ~(size_t)63; }
+size_t dw_list_bytes(int B, int T, int U1, int gran)
+{
+    const size_t n_gran = ((size_t)B * T * U1 + gran - 1) / gran;
+    const size_t nblk = (n_gran + DWL_BLK - 1) / DWL_BLK;
+    return 64 + dwl_tab_bytes(B) + ((nblk * 4 + 63) & ~(size_t)63) + (n_gran + 16) * 4;
+}
+const int *dw_list_ptr(const void *region, int B, int T, int U1, int gran)
+{
+    const long n_gran = ((long)B * T * U1 + gran - 1) / gran;
+    const size_t nblk = (size_t)((n_gran + DWL_BLK - 1) / DWL_BLK);
+    return (const int *)((const char *)region + 64 + dwl_tab_bytes(B) + ((nblk * 4 + 63) & ~(size_t)63));
+}
+void launch_dw_list(const int32_t *logit_lens, const int32_t *target_lens, int B, int T, int U1, int gran,
+                    void *region, hipStream_t st)
+{
+    const long n_gran = ((long)B * T * U1 + gran - 1) / gran;
+    const int nblk = (int)((n_gran + DWL_BLK - 1) / DWL_BLK);
+    long *head = (long *)region;
+    long *tab = head + 8;
+    int *blk = (int *)((char *)region + 64 + dwl_tab_bytes(B));
+    int *list = const_cast<int *>(dw_list_ptr(region, B, T, U1, gran));
+    launch_dw_table(logit_lens, B, T, U1, gran, tab, st);
+    hipLaunchKernelGGL(k_dw_list_count, dim3(nblk), dim3(DWL_BLK), 0, st, logit_lens, target_lens, B, T, U1, gran, n_gran, blk);
+    hipLaunchKernelGGL(k_dw_list_scan, dim3(1), dim3(1024), 0, st, blk, nblk, head, tab, B);
+    hipLaunchKernelGGL(k_dw_list_write, dim3(nblk), dim3(DWL_BLK), 0, st, logit_lens, target_lens, B, T, U1, gran, n_gran, blk, list);
+}
+
 int dw_tiles(int H, int V)
 {
     const int nv = (V + 127) / 128, nh = (H + 127) / 128;
     return (nh / 2) * ((nv + 1) / 2) + (nh & 1) * ((nv + 3) / 4);
 }
 
+template <bool LIST>
 __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -845,12 +953,12 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
     const int v0 = vt * 128, h0 = ht * 128;
     const int vbase = v0 + 4 * i, hbase = h0 + 4 * i;
     const bool vok = vbase < V, hok = hbase < H;
-    // this split's share of the LIVE granules (k_dw_table), walked utterance by utterance
-    const long *tab = a.dw_tab;
-    const int B = a.B;
-    const long nlive = tab[2 * B + 1];
-    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
-
+    // Two K walks, chosen on the DEVICE by the list builder (head[1]): batches whose live time steps
+    // hold no dead granule (all target lengths full, or nearly) take the contiguous-range walk — one
+    // running pointer, nothing but pointer increments between the MFMAs; ragged batches take the
+    // live-granule list (≈14 scalar instructions per 128 MFMAs more, ≈1 %, for every dead granule
+    // skipped).  The kernel is launched once per mode; the launch whose mode is not selected exits.
+    if ((((const long *)a.dw_tab)[1] != 0) != LIST) return;
     f32x16 acc[4][4];
 #pragma unroll
     for (int qm = 0; qm < 4; ++qm)
@@ -859,6 +967,87 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LIST) {
+    // this split's share of the LIVE granules (launch_dw_list): a contiguous piece of the list
+    const long nlive = ((const long *)a.dw_tab)[0];
+    const int *__restrict__ lst = a.dw_list;
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+
+
+    if (g_hi > g_lo) {  // workgroup-uniform
+        // columns beyond V / H (edge tiles) re-read the last valid 16 bytes: they only feed
+        // accumulators that are never stored.
+        const float *gbase = a.logits + (long)half * V + (vok ? vbase : V - 4);
+        const float *hbase_p = a.hidden + (long)half * H + (hok ? hbase : H - 4);
+        const long gstep = 2L * V, hstep = 2L * H;
+        const long ggran = (long)DW_KC * V, hgran = (long)DW_KC * H;  // floats per granule
+        // Register ring of DW_RING k-steps = ONE granule (16 cells).  The MFMAs read their ring slot
+        // directly; the slot is refilled one k-step LATER, from inside the next k-step's MFMA stream
+        // (its own MFMAs have all issued by then, so the load does not wait on them), and the
+        // bias-gradient adds ride between MFMAs too: nothing stands in front of a k-step's 16 MFMAs.
+        // Slot 7 is refilled with the CURRENT granule's last k-step, slots 0-6 with the NEXT live
+        // granule's k-steps 0-6 — wherever the list says that granule lies: the stream runs on
+        // across dead stretches without a pipeline restart.
+        // (Earlier forms: copy the slot out + refill in front of the MFMAs 47.4 ms; refill right
+        // behind its own MFMAs 50.7 ms; inline-asm loads: hipcc copies pending destinations.)
+        // The loop body is rotated by one k-step — k-steps 1..7 of granule r, then k-step 0 of granule
+        // r+1 — so that all eight refills of an iteration read the SAME granule (r+1) through one
+        // pointer; with two pointers in the body hipcc copied the ring at the back-edge behind a
+        // vmcnt(0), draining it every round.
+        const long g0 = lst[g_lo];
+        const float *gc = gbase + g0 * ggran, *hc = hbase_p + g0 * hgran;
+        f32x4 ra[DW_RING], rb[DW_RING];
+#pragma unroll
+        for (int s_ = 0; s_ < DW_RING; ++s_) {
+            ra[s_] = *(const f32x4 *)(gc + s_ * gstep);
+            rb[s_] = *(const f32x4 *)(hc + s_ * hstep);
+        }
+        // one k-step: 16 MFMAs from slot SL, the refill of slot RF (if any) behind the first row of
+        // MFMAs, the bias-gradient adds between the others
+#define DW_KSTEP(SL, REFILL)                                                                              \
+        do {                                                                                              \
+            auto row = [&](int qm) {                                                                      \
+                _Pragma("unroll") for (int qn = 0; qn < 4; ++qn)                                          \
+                    acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SL][qm], rb[SL][qn], acc[qm][qn], 0, 0, 0); \
+            };                                                                                            \
+            row(0);                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            REFILL;                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            row(1);                                                                                       \
+            dbacc[0] += ra[SL][0];                                                                        \
+            dbacc[1] += ra[SL][1];                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            row(2);                                                                                       \
+            dbacc[2] += ra[SL][2];                                                                        \
+            dbacc[3] += ra[SL][3];                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            row(3);                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        } while (0)
+        DW_KSTEP(0, (void)0);
+        for (long r = g_lo; r + 1 < g_hi; ++r) {
+            const long gn_i = lst[r + 1];  // the next live granule, wherever it lies
+            const float *gn = gbase + gn_i * ggran, *hn = hbase_p + gn_i * hgran;
+#pragma unroll
+            for (int s_ = 1; s_ < DW_RING; ++s_)
+                DW_KSTEP(s_, (ra[s_ - 1] = *(const f32x4 *)(gn + (s_ - 1) * gstep),
+                              rb[s_ - 1] = *(const f32x4 *)(hn + (s_ - 1) * hstep)));
+            DW_KSTEP(0, (ra[DW_RING - 1] = *(const f32x4 *)(gn + (DW_RING - 1) * gstep),
+                         rb[DW_RING - 1] = *(const f32x4 *)(hn + (DW_RING - 1) * hstep)));
+        }
+#pragma unroll
+        for (int s_ = 1; s_ < DW_RING; ++s_) DW_KSTEP(s_, (void)0);
+#undef DW_KSTEP
+    }
+
+    } else {
+    // this split's share of the LIVE granules (k_dw_table), walked utterance by utterance
+    const long *tab = a.dw_tab + 8;  // the table sits 64 bytes into the region (head words first)
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+
 
     int ub = 0;
     while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;  // utterance holding live granule g_lo
@@ -922,6 +1111,7 @@ __global__ __launch_bounds__(256, 1) void k_dw(JointBwdArgs a)
         }
     }
 
+    }
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V]
     float *sw = a.slab_w + (long)split * V * H;
     if (hok) {
@@ -960,8 +1150,11 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ 
 
 void launch_dw(const JointBwdArgs &a, hipStream_t st)
 {
-    launch_dw_table(a.logit_lens, a.B, a.T, a.U1, DW_KC, a.dw_tab, st);
-    hipLaunchKernelGGL(k_dw, dim3(dw_tiles(a.H, a.V) * a.n_split), dim3(256), 0, st, a);
+    launch_dw_list(a.logit_lens, a.target_lens, a.B, a.T, a.U1, DW_KC, a.dw_tab, st);
+    JointBwdArgs b = a;
+    b.dw_list = dw_list_ptr(a.dw_tab, a.B, a.T, a.U1, DW_KC);
+    hipLaunchKernelGGL(k_dw<false>, dim3(dw_tiles(a.H, a.V) * a.n_split), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_dw<true>, dim3(dw_tiles(a.H, a.V) * a.n_split), dim3(256), 0, st, b);
 }
 
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st)

@@ -509,6 +509,18 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     const float *erow = USE_HID ? a.hidden + ((long)b * T * U1 + crow) * H + 4 * half
                                   : a.enc + (long)b * a.enc_sb + (long)trow * a.enc_st + 4 * half;
     const float *prow = a.pred + ((long)b * U1 + urow) * H + 4 * half;
+    // Ragged batches: a wave whose 32 rows all lie outside the lattice (u > U_b, or past the live
+    // cells of the tile) has nothing to compute — its logits are never read (k_dhidden_gen loads live
+    // rows only and zero-fills G itself).  The default main loop has no barrier, so such a wave simply
+    // skips it (and its epilogue) and its SIMD goes to the co-resident workgroup; the workgroup-wide
+    // barriers of the finalisation are outside the skipped region.
+    bool wave_dead = false;
+#ifndef RNNT_NO_WAVESKIP
+    if (WITH_LOSS && BREG) {
+        const int myrow = m0 + wm * 32 + i;
+        wave_dead = __all(myrow >= ncell || urow > Ub);
+    }
+#endif
     const int HK = (H + 7) / 8, NG = (V + 127) / 128;
     const long wstride = (long)NG * 256;  // float4 per 8-wide k chunk
     const int npass = (NG + 3) / 4;
@@ -534,6 +546,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
         const f32x4 *wpass = (const f32x4 *)a.wpack + (long)pass * 1024;
         const int gvalid = min(4, NG - pass * 4);
         STAMP(1 + 2 * (pass & 1));
+        if (wave_dead) continue;  // wave-uniform
         __builtin_amdgcn_s_setprio(0);
         fwd_mainloop<USE_HID, PAIRS, BREG>(erow, prow, wpass, gvalid, HK, wstride, H, half, wave, lane, wn,
                                 s_b, acc);
@@ -611,8 +624,8 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
         __syncthreads();  // also drains this workgroup's logits stores (vmcnt(0))
         if (tid < FWD_ROWS) {
             const int c = m0 + tid;
-            if (c < ncell) {
-                const int t = c / U1, u = c - t * U1;
+            const int t = c / U1, u = c - t * U1;
+            if (c < ncell && u <= Ub) {  // cells past U_b are no lattice cells: nothing reads their slots
                 const float ma = s_m[0][tid], mb = s_m[1][tid];
                 const float m = fmaxf(ma, mb);
                 const float ea = (ma == RNNT_NEG_INF) ? 0.f : __expf(ma - m);

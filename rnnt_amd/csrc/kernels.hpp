@@ -63,7 +63,8 @@ struct JointBwdArgs {
     int B, T, U1, H, V, blank;
     int n_ublk, n_ttile, n_split;
     unsigned *counter;  // 8 x 64 zeroed bytes: per-XCD work-item counters of the persistent kernels
-    long *dw_tab;       // 2B+2 longs: live-row table of k_dw (k_dw_table)
+    long *dw_tab;       // dW live-granule region (launch_dw_list): [0] live count, block offsets, list
+    const int *dw_list; // set by launch_dw: the list inside that region
     int n_cu;           // compute units (grid size of the persistent kernels)
     int flags;          // bit 4 (16): G is produced by k_dhidden_gen; others: experiment switches
     int pred_split_col; // dPred slabs: columns < this come in 8-row t tiles (k_dhidden_gen, bf16 route), the rest in 4-row tiles (k_dhidden)
@@ -73,6 +74,7 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st);
 void launch_dw(const JointBwdArgs &a, hipStream_t st);
 int dw_tiles(int H, int V);  // workgroup tiles per split of k_dw
 void launch_dw_table(const int32_t *logit_lens, int B, int T, int U1, int gran, long *tab, hipStream_t st);
+size_t dw_list_bytes(int B, int T, int U1, int gran);  // bytes of the live-granule region of launch_dw
 void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);

@@ -427,6 +427,20 @@ def test_forward_kernel_variants_agree_bitwise(amd, shape):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("H,V", [(64, 96), (640, 64), (128, 260)])
+def test_short_targets_skip_dead_rows_vs_oracle(amd, H, V):
+    """Utterances whose targets are much shorter than U: most cells of every live time step lie past
+    U_b.  The forward skips wave tiles without a lattice cell, dW walks the device-built list of live
+    16-cell granules (the list walk, not the contiguous-range one), dHidden skips u blocks past U_b."""
+    d = make_inputs(5, 37, 100, H, V, seed=H + V)
+    d["logit_lens"] = np.array([37, 20, 37, 1, 30], dtype=np.int32)
+    d["target_lens"] = np.array([100, 7, 0, 55, 16], dtype=np.int32)
+    _compare(_run_fused(amd, d), oracle_fused(d))
+    # all targets full but ragged time steps: the contiguous-range walk
+    d["target_lens"] = np.full(5, 100, dtype=np.int32)
+    _compare(_run_fused(amd, d), oracle_fused(d))
+
+
 def test_forward_only_costs_match_and_skip_backward(amd):
     """torch.no_grad() / no input requires grad: RNNTModel.forward's loss comes from the forward
     kernels alone (rnnt_engine_joint_loss_fwd) and equals the training-mode loss bit for bit."""
