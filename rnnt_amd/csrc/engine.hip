@@ -84,8 +84,9 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     const size_t rows_pad = dtype == RNNT_DTYPE_BF16 ? (cells + 1 + 31) / 32 * 32 : (cells + 1 + 15) / 16 * 16;
     L->rows_pad = rows_pad;
     L->D = (int)D;
-    L->n_ublk = (U1 + 15) / 16;
-    L->n_ttile = (T + 3) / 4;
+    // dEnc slabs: one per u block; the fp32 route's fused dHidden kernel may use 8-wide blocks
+    L->n_ublk = dtype == RNNT_DTYPE_BF16 ? (U1 + 15) / 16 : (U1 + dhidden_gen_bu(T, U1) - 1) / dhidden_gen_bu(T, U1);
+    L->n_ttile = (T + 3) / 4;  // dPred slabs: at most one per 4 t rows (the persistent kernel's 16-wide items)
     L->n_split = dw_splits(B, T, H, V, dtype);
     size_t o = 0;
     if (dtype == RNNT_DTYPE_BF16) {
@@ -208,6 +209,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = blank;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
     g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = xflags & ~16; g.debug = g_debug; g.pred_split_col = 0;
+    g.gen_bu = dtype == RNNT_DTYPE_BF16 ? 16 : dhidden_gen_bu(T, U1);  // u width of the dHidden tiles
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;
         h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;
@@ -411,7 +413,7 @@ int rnnt_engine_joint_bwd(const void *enc, const int64_t enc_strides[3], const v
     g.B = B; g.T = T; g.U1 = U1; g.H = H; g.V = V; g.blank = V - 1;
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
     g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024);
-    g.n_cu = device_cus(); g.flags = 0; g.debug = nullptr;
+    g.n_cu = device_cus(); g.flags = 0; g.debug = nullptr; g.gen_bu = dhidden_gen_bu(T, U1);
     launch_make_hidden(g, st);
     launch_dhidden(g, st);
     launch_dhidden_reduce(g, st);

@@ -56,12 +56,15 @@ struct PwChunk {
 
 // `cb0`: first 128-column block this launch covers (0, or 4 when k_dhidden_gen has produced G and
 // the first 512 columns: H > 512).
+// BU: u width of an item (16: 4 t x 16 u; 8: 8 t x 8 u for short targets, as k_dhidden_gen<8>).
+template <int BU>
 __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a, int cb0)
 {
+    constexpr int IT = 64 / BU;  // t rows per item
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
-    const int n_cb = (H + 127) / 128 - cb0, n_ub = (U1 + DH_BU - 1) / DH_BU, n_tt = (T + PW_BT - 1) / PW_BT;
+    const int n_cb = (H + 127) / 128 - cb0, n_ub = (U1 + BU - 1) / BU, n_tt = (T + IT - 1) / IT;
     const long zero_row = (long)a.B * T * U1;  // first padding row: G == 0
     // V % 8 == 4: in the last chunk lanes 32-63 would start at k >= V; they step back 4
     // (valid addresses) and their G values are zeroed
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a, int cb0)
         const int tt = (int)(r_ % n_tt);
         const int b = (int)(r_ / n_tt);
         const int Tb = len_t(a.logit_lens, b, a.T);
-        const int t0 = tt * PW_BT, u0 = ub * DH_BU;
+        const int t0 = tt * IT, u0 = ub * BU;
         if (t0 >= Tb) continue;  // wave-uniform
         // a u block past U_b holds no lattice cell (G == 0 there): its slabs are never read
         // (k_reduce_enc / k_reduce_pred stop at U_b)
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a, int cb0)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int row = mt * 32 + i;
-            const int t = t0 + (row >> 4), u = u0 + (row & 15);
+            const int t = t0 + row / BU, u = u0 + row % BU;
             const long cell = (t < T && u < U1) ? ((long)b * T + t) * U1 + u : zero_row;
             gptr[mt] = a.logits + cell * V + 4 * half;
         }
@@ -175,45 +178,55 @@ __global__ __launch_bounds__(512, 2) void k_dhidden(JointBwdArgs a, int cb0)
             if (acc[0][0][0] == 12345.f) a.slab_enc[0] = acc[1][3][7];
             continue;
         }
-        // ---- epilogue (in-wave): dPre = dHidden * (1 - hidden^2); sum over u and over t
-        float psum[8][4];
+        // ---- epilogue (in-wave): dPre = dHidden * (1 - hidden^2); sum over u and over t.
+        // Register 8 rh + r7 of M tile mt: BU = 16: t row 2 mt + rh, u slot 8 (r7>>2) + (r7&3) + 4 half;
+        // BU = 8: t row 4 mt + 2 rh + (r7>>2), u slot (r7&3) + 4 half.
+        constexpr int NU = BU / 2, TB = BU == 16 ? 1 : 2;
+        float psum[NU][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < NU; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) psum[k][q] = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
-                const int t = t0 + mt * 2 + rh;
-                const bool tok = t < Tb;
-                float esum[4] = {0.f, 0.f, 0.f, 0.f};
+                float esum[TB][4];
+#pragma unroll
+                for (int e = 0; e < TB; ++e)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) esum[e][q] = 0.f;
 #pragma unroll
                 for (int r7 = 0; r7 < 8; ++r7) {
-                    const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
-                    const bool ok = tok && u < U1 && colok;
+                    const int t = t0 + (BU == 16 ? mt * 2 + rh : mt * 4 + 2 * rh + (r7 >> 2));
+                    const int u = u0 + (BU == 16 ? 8 * (r7 >> 2) + (r7 & 3) : (r7 & 3)) + 4 * half;
+                    const bool ok = t < Tb && u < U1 && colok;
                     f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
                     if (ok) h4 = *(const f32x4 *)(a.hidden + (((long)b * T + t) * U1 + u) * H + col);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float d = ok ? acc[mt][q][rh * 8 + r7] * (1.f - h4[q] * h4[q]) : 0.f;
-                        esum[q] += d;
-                        psum[r7][q] += d;
+                        esum[BU == 16 ? 0 : (r7 >> 2)][q] += d;
+                        psum[BU == 16 ? r7 : (r7 & 3)][q] += d;
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
-                if (half == 0 && tok && colok) {
-                    f32x4 o = {esum[0], esum[1], esum[2], esum[3]};
-                    *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + col) = o;
+                for (int e = 0; e < TB; ++e) {
+                    const int t = t0 + (BU == 16 ? mt * 2 + rh : mt * 4 + 2 * rh + e);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) esum[e][q] += __shfl_xor(esum[e][q], 32, 64);
+                    if (half == 0 && t < Tb && colok) {
+                        f32x4 o = {esum[e][0], esum[e][1], esum[e][2], esum[e][3]};
+                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + col) = o;
+                    }
                 }
             }
         if (colok) {
 #pragma unroll
-            for (int r7 = 0; r7 < 8; ++r7) {
-                const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+            for (int k = 0; k < NU; ++k) {
+                const int u = u0 + (BU == 16 ? 8 * (k >> 2) + (k & 3) : k) + 4 * half;
                 if (u < U1) {
-                    f32x4 o = {psum[r7][0], psum[r7][1], psum[r7][2], psum[r7][3]};
+                    f32x4 o = {psum[k][0], psum[k][1], psum[k][2], psum[k][3]};
                     *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + col) = o;
                 }
             }
@@ -252,8 +265,12 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #else
 #define GSTAMP(slot) do {} while (0)
 #endif
+// BU = u width of the tile (16: 8 t x 16 u; 8: 16 t x 8 u, for short targets — U1 = 101 fills 7 blocks
+// of 16 with 10 % dead rows, 13 blocks of 8 with 3 %); an M tile of 32 rows is (32/BU) t rows of BU u.
+template <int BU>
 __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 {
+    constexpr int BT = 128 / BU;  // t rows per tile
     __shared__ __attribute__((aligned(16))) float smem[4 * 4 * 256 + 2 * 64 * 65];  // 4-slot G exchange + epilogue
     float(*s_red)[64][65] = (float(*)[64][65])(smem + 4 * 4 * 256);
 
@@ -264,12 +281,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
     const int Tb = len_t(a.logit_lens, b, a.T);
-    const int t0 = tt * DG_BT, u0 = ub * DH_BU;
+    const int t0 = tt * BT, u0 = ub * BU;
     const int VK = V / 8;
 
     // ---- this lane's producer row (M-tile `wave`, row i): one lattice cell or none
     const int prow = wave * 32 + i;
-    const int pt = t0 + (prow >> 4), pu = u0 + (prow & 15);
+    const int pt = t0 + prow / BU, pu = u0 + prow % BU;
     const bool pexists = pt < T && pu < U1;
     const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : (long)a.B * T * U1;  // else zero row
     float *lptr = (float *)a.logits + pcell * V + 4 * half;
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         // k_dw only walks the live rows, rounded out to 16-cell granules (k_dw_table): up to 15
         // cells past this utterance's live end, and up to 15 cells before the next utterance's
         // first cell (= the last cells of this one).  Tiles that touch neither stay unwritten.
-        if ((long)t0 * U1 >= (long)Tb * U1 + DW_KC && (long)(t0 + DG_BT) * U1 <= (long)T * U1 - DW_KC) return;
+        if ((long)t0 * U1 >= (long)Tb * U1 + DW_KC && (long)(t0 + BT) * U1 <= (long)T * U1 - DW_KC) return;
         if (pexists) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;
@@ -312,10 +329,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     // their stores are dropped, so neither needs a branch or an exec mask.
     const long cell0 = ((long)b * T + t0) * U1 + u0;
     const long rows_left = a.rows_pad + 16 - cell0;  // rows of the allocation from cell0 on
-    const long span_rows = (long)(DG_BT - 1) * U1 + DH_BU < rows_left ? (long)(DG_BT - 1) * U1 + DH_BU : rows_left;
+    const long span_rows = (long)(BT - 1) * U1 + BU < rows_left ? (long)(BT - 1) * U1 + BU : rows_left;
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.logits + cell0 * V), 0, (int)(span_rows * V * 4), 0x00020000);
-    const unsigned lane_row_off = (unsigned)((((prow >> 4) * U1 + (prow & 15)) * (long)V + 4 * half) * 4);
+    const unsigned lane_row_off = (unsigned)((((prow / BU) * U1 + (prow % BU)) * (long)V + 4 * half) * 4);
     const unsigned xvoff = live ? lane_row_off : 0xfffffff0u;    // loads: rows of the lattice only
     const unsigned svoff = pexists ? lane_row_off : 0xfffffff0u;  // stores: every existing cell
     const unsigned woff[2] = {(unsigned)(((4 * half) * H + (colok[0] ? colg[0] : 0)) * 4),
@@ -509,9 +526,15 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 
     // ---- epilogue: dPre = dHidden * (1 - hidden^2); reduce over u (dEnc) and over t (dPred)
     if (RNNT_XP(a.flags, 8192)) return;  // experiment switch
-    float psum[8][8];
+    // Accumulator register rr = 8 rh + r7 of M tile (2 wm + mt) is row (rr&3) + 8 (rr>>2) + 4 half of
+    // its 32: BU = 16: t row rh, u slot 8 (r7>>2) + (r7&3) + 4 half;  BU = 8: t row 2 rh + (r7>>2), u
+    // slot (r7&3) + 4 half.  A batch = (mt, rh) = 8 registers = 16 hidden loads.
+    constexpr int TPM = 32 / BU;        // t rows per M tile
+    constexpr int NU = BU / 2;          // u slots per lane half
+    constexpr int TB = BU == 16 ? 1 : 2;  // t rows per batch
+    float psum[NU][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < NU; ++k)
 #pragma unroll
         for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
@@ -519,16 +542,18 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         (void *)(a.hidden + cell0 * H), 0, (int)(span_rows * H * 4), 0x00020000);
     const unsigned hvoff[2] = {colok[0] ? (unsigned)(((4 * half) * H + colg[0]) * 4) : 0xfffffff0u,
                                colok[1] ? (unsigned)(((4 * half) * H + colg[1]) * 4) : 0xfffffff0u};
-    // Four batches (one t-row of the wave each) of 16 hidden loads, two batches in flight: each
-    // batch otherwise waits out a full memory round trip (4 x ~6 000 cycles per tile, stamps).
+    auto t_of = [&](int mt, int rh, int r7) { return (2 * wm + mt) * TPM + (BU == 16 ? rh : 2 * rh + (r7 >> 2)); };  // t row inside the tile
+    auto us_of = [&](int r7) { return BU == 16 ? 8 * (r7 >> 2) + (r7 & 3) : (r7 & 3); };  // u slot without the lane half
+    // Four batches of 16 hidden loads, two batches in flight: each batch otherwise waits out a full
+    // memory round trip (4 x ~6 000 cycles per tile, stamps).
     auto hload = [&](int k, f32x4 (&hb)[16]) {  // k = mt*2 + rh
+        const int mt = k >> 1, rh = k & 1;
 #pragma unroll
         for (int r7 = 0; r7 < 8; ++r7) {
-            // hidden row of (t, u = u0 + 8(r7>>2) + 4half + (r7&3)) through the tile buffer:
-            // scalar row offset + per-lane (half, column) offset, no predicate — rows outside
-            // the lattice have G = 0, hence an exactly zero accumulator, whatever (finite, or
-            // out of range -> 0) hidden value they meet
-            const unsigned soff = (unsigned)(((wm * 4 + k) * U1 + 8 * (r7 >> 2) + (r7 & 3)) * H) * 4u;
+            // hidden row of (t, u) through the tile buffer: scalar row offset + per-lane (half,
+            // column) offset, no predicate — rows outside the lattice have G = 0, hence an exactly
+            // zero accumulator, whatever (finite, or out of range -> 0) hidden value they meet
+            const unsigned soff = (unsigned)((t_of(mt, rh, r7) * U1 + us_of(r7)) * H) * 4u;
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 hb[r7 * 2 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hvoff[g], soff, 0));
@@ -536,9 +561,11 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     };
     auto hcomp = [&](int k, const f32x4 (&hb)[16]) {
         const int mt = k >> 1, rh = k & 1;
-        const int t = t0 + wm * 4 + k;
-        const bool tok = t < Tb;
-        float esum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float esum[TB][8];
+#pragma unroll
+        for (int e = 0; e < TB; ++e)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[e][q] = 0.f;
 #pragma unroll
         for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
@@ -547,19 +574,23 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float d = acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - h4[q] * h4[q]);
-                    esum[g * 4 + q] += d;
-                    psum[r7][g * 4 + q] += d;
+                    esum[BU == 16 ? 0 : (r7 >> 2)][g * 4 + q] += d;
+                    psum[BU == 16 ? r7 : (r7 & 3)][g * 4 + q] += d;
                 }
             }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
-        if (half == 0 && tok) {
+        for (int e = 0; e < TB; ++e) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-                if (colok[g]) {
-                    f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
-                    *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
-                }
+            for (int q = 0; q < 8; ++q) esum[e][q] += __shfl_xor(esum[e][q], 32, 64);
+            const int t = t0 + t_of(mt, rh, 4 * e);
+            if (half == 0 && t < Tb) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o = {esum[e][g * 4], esum[e][g * 4 + 1], esum[e][g * 4 + 2], esum[e][g * 4 + 3]};
+                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
+                    }
+            }
         }
     };
     {
@@ -580,15 +611,15 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     }
     if (wm == 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < NU; ++k)
 #pragma unroll
             for (int q = 0; q < 8; ++q) s_red[wn][lane][k * 8 + q] = psum[k][q];
     }
     __syncthreads();
     if (wm == 0) {
 #pragma unroll
-        for (int r7 = 0; r7 < 8; ++r7) {
-            const int u = u0 + 8 * (r7 >> 2) + 4 * half + (r7 & 3);
+        for (int k = 0; k < NU; ++k) {
+            const int u = u0 + (BU == 16 ? 8 * (k >> 2) + (k & 3) : k) + 4 * half;
             if (u < U1) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
@@ -596,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                         f32x4 o;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            o[q] = psum[r7][g * 4 + q] + s_red[wn][lane][r7 * 8 + g * 4 + q];
+                            o[q] = psum[k][g * 4 + q] + s_red[wn][lane][k * 8 + g * 4 + q];
                         *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + colg[g]) = o;
                     }
             }
@@ -608,9 +639,16 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 // k_dhidden_gen applies: V in whole 32-wide chunk quadruples, and its raw buffers (num_records is
 // 32-bit, per-lane offsets are 32-bit) can span W and one tile's logits / hidden rows.  It covers
 // the first 512 columns of H; launch_dhidden sends the rest to k_dhidden.
+// u width of k_dhidden_gen's tiles: the one that pads the (T, U1) lattice least
+int dhidden_gen_bu(int T, int U1)
+{
+    const long c16 = (long)((U1 + 15) / 16 * 16) * ((T + 7) / 8 * 8);
+    const long c8 = (long)((U1 + 7) / 8 * 8) * ((T + 15) / 16 * 16);
+    return c8 < c16 ? 8 : 16;
+}
 bool dhidden_gen_ok(int H, int V, int U1)
 {
-    const long span_rows = (long)(DG_BT - 1) * U1 + DH_BU;
+    const long span_rows = (long)(16 - 1) * U1 + 16;  // the taller tile form (16 t x 8 u)
     const long wide = V > H ? V : H;
     return (V % 32) == 0 && (long)V * H * 4 < 0xffffffffL && span_rows * wide * 4 < 0x7fffffffL;
 }
@@ -621,7 +659,7 @@ __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ sl
                                                     const int32_t *__restrict__ logit_lens,
                                                     const int32_t *__restrict__ target_lens,
                                                     float *__restrict__ out, int B, int T, int U1,
-                                                    int H, int n_ublk)
+                                                    int H, int n_ublk, int bu_lo, int col_split)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
     const int H4 = H / 4;
@@ -633,7 +671,9 @@ __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ sl
     if (t < len_t(logit_lens, b, T)) {
         // u blocks that start past U_b hold no lattice cell; the fused dHidden kernels skip them
         // without writing their slab
-        int nub = len_u(target_lens, b, U1) / DH_BU + 1;
+        // slabs written: u blocks of width bu_lo (both dHidden kernels use the same u width)
+        const int bu = bu_lo;
+        int nub = len_u(target_lens, b, U1) / bu + 1;
         if (nub > n_ublk) nub = n_ublk;
         for (int k = 0; k < nub; ++k) s += ((const f32x4 *)slab)[(long)k * n + idx];
     }
@@ -668,25 +708,31 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
         // zero the padding rows k_dw may touch (k_make_g used to)
         const long cells = (long)a.B * a.T * a.U1;
         (void)hipMemsetAsync((float *)a.logits + cells * a.V, 0, (size_t)(a.rows_pad + 16 - cells) * a.V * 4, st);
-        dim3 grid(a.n_ublk, (a.T + DG_BT - 1) / DG_BT, a.B);
-        hipLaunchKernelGGL(k_dhidden_gen, grid, dim3(256), 0, st, a);
+        if (a.gen_bu == 8) {
+            dim3 grid((a.U1 + 7) / 8, (a.T + 15) / 16, a.B);
+            hipLaunchKernelGGL(k_dhidden_gen<8>, grid, dim3(256), 0, st, a);
+        } else {
+            dim3 grid((a.U1 + 15) / 16, (a.T + DG_BT - 1) / DG_BT, a.B);
+            hipLaunchKernelGGL(k_dhidden_gen<16>, grid, dim3(256), 0, st, a);
+        }
         if (a.H <= DG_COLS) return;
         // H > 512 (the reference's joint is 1024 wide): G now stands in place of the logits; the
         // remaining column blocks are plain G x W products for the persistent kernel
     }
     (void)hipMemsetAsync(a.counter, 0, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
-    hipLaunchKernelGGL(k_dhidden, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
+    if (a.gen_bu == 8) hipLaunchKernelGGL(k_dhidden<8>, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
+    else hipLaunchKernelGGL(k_dhidden<16>, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
 }
 
 void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)
 {
     const long n4e = (long)a.B * a.T * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_enc, dim3((unsigned)((n4e + 255) / 256)), dim3(256), 0, st,
-                       a.slab_enc, a.logit_lens, a.target_lens, a.grad_enc, a.B, a.T, a.U1, a.H, a.n_ublk);
+                       a.slab_enc, a.logit_lens, a.target_lens, a.grad_enc, a.B, a.T, a.U1, a.H, a.n_ublk, a.gen_bu, a.pred_split_col);
     const long n4p = (long)a.B * a.U1 * (a.H / 4);
     hipLaunchKernelGGL(k_reduce_pred, dim3((unsigned)((n4p + 255) / 256)), dim3(256), 0, st,
                        a.slab_pred, a.logit_lens, a.target_lens, a.grad_pred, a.B, a.T, a.U1, a.H,
-                       DG_BT, PW_BT, a.pred_split_col);
+                       128 / a.gen_bu, 64 / a.gen_bu, a.pred_split_col);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct JointBwdArgs {
     const int *dw_list; // set by launch_dw: the list inside that region
     int n_cu;           // compute units (grid size of the persistent kernels)
     int flags;          // bit 4 (16): G is produced by k_dhidden_gen; others: experiment switches
+    int gen_bu;         // u width of k_dhidden_gen's tiles (16, or 8 for short targets); dEnc slabs of columns < pred_split_col
     int pred_split_col; // dPred slabs: columns < this come in 8-row t tiles (k_dhidden_gen, bf16 route), the rest in 4-row tiles (k_dhidden)
     unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
 };
@@ -79,7 +80,8 @@ void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
 void launch_make_g(const JointBwdArgs &a, hipStream_t st);
-bool dhidden_gen_ok(int H, int V, int U1);  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
+bool dhidden_gen_ok(int H, int V, int U1);
+int dhidden_gen_bu(int T, int U1);  // 16 or 8: the tile form that pads the lattice least  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
 
 // ---- bf16.hip (RNNT_DTYPE_BF16 route: bf16 GEMM operands, fp32 accumulate / logits / loss)
 struct Bf16Args {
