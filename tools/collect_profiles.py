@@ -45,7 +45,7 @@ def pick(d, key):
     assert len(ks) == 1, (key, list(d))
     return d[ks[0]]
 
-names = {"cfg2": ("fp32", {"joint_fwd_gemm": "k_joint_fwd_persist<", "dhidden_gemm": "k_dhidden_gen", "dw_gemm": "k_dw"}),
+names = {"cfg2": ("fp32", {"joint_fwd_gemm": "k_joint_fwd_persist<", "dhidden_gemm": "k_dhidden_gen", "dw_gemm": "k_dw<false>"}),
          "cfg2_bf16": ("bf16", {"joint_fwd_gemm": "k_joint_fwd_bf16", "dhidden_gemm": "k_dhidden_bf16", "dw_gemm": "k_dw_bf16"})}
 alg = {"cfg2": {"joint_fwd_gemm": cells * (4 * H + 4 * H + 4 * V),  # writes hidden, reads it back, writes logits
                 "dhidden_gemm": cells * (4 * V + 4 * H + 4 * V) + 2.5e9,  # logits in, hidden in, G out, dEnc/dPred slabs
@@ -61,12 +61,7 @@ for key, (dt, ks) in names.items():
     f, w = counters(dt, "FETCH_SIZE"), counters(dt, "WRITE_SIZE")
     out[key] = {}
     for stage, kn in ks.items():
-        if kn == "k_dw":
-            fk = {k: v for k, v in f.items() if k == "k_dw"}
-            wk = {k: v for k, v in w.items() if k == "k_dw"}
-            fr, wr = pick(fk, "k_dw"), pick(wk, "k_dw")
-        else:
-            fr, wr = pick(f, kn), pick(w, kn)
+        fr, wr = pick(f, kn), pick(w, kn)  # "k_dw<false>": the contiguous-range walk (full-length batches)
         out[key][stage] = {"fetch_raw": int(fr * 1024), "write": int(wr * 1024), "algorithmic": int(alg[key][stage])}
 json.dump(out, open(os.path.join(dst, f"{rnd}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
@@ -86,7 +81,7 @@ if os.path.exists(sq_path):
                 "# means over the full-size launches of each SHIPPED kernel.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES /\n"
                 "# (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): fraction of the chip's matrix-pipe cycles that carried an MFMA.\n")
         for k, c in blocks.items():
-            if not any(x in k for x in ("k_joint_fwd_persist", "k_dhidden_gen", "k_dw")) or "table" in k:
+            if not any(x in k for x in ("k_joint_fwd_persist", "k_dhidden_gen", "k_dw<false>")):
                 continue
             f.write(k + "\n")
             for n, v in sorted(c.items()):
@@ -96,4 +91,5 @@ if os.path.exists(sq_path):
     print(open(os.path.join(dst, f"{rnd}_sq_counters_pmc.txt")).read())
 for extra in ("ref1024.json", "cfg4.json", "ref1024.kernel_stats.csv", "ref1024.bf16.json"):
     if os.path.exists(os.path.join(src, f"{tag}.{extra}")):
-        cp(f"{tag}.{extra}", f"{rnd}_{extra.replace(".bf16", "_bf16").replace(".json", "_bench.json").replace('.kernel_stats.csv', '_kernel_stats.csv')}")
+        out_name = extra.replace(".bf16", "_bf16").replace(".json", "_bench.json").replace(".kernel_stats.csv", "_kernel_stats.csv")
+        cp(f"{tag}.{extra}", f"{rnd}_{out_name}")
