@@ -17,9 +17,13 @@
  * log-softmax gradient are restated from the published algorithm (Graves 2012,
  * "Sequence Transduction with Recurrent Neural Networks") in the form SURVEY.md §8c
  * records.  The reference's own tests hold NO golden vectors for this path,
- * so the LOSS half is pinned only by (a) brute-force alignment enumeration
- * (oracle/brute_force.py) and (b) torch autograd through an independent log-space alpha
- * recursion (oracle/torch_check.py): "parity unpinned" against torchaudio itself.
+ * so the LOSS half is pinned by (a) brute-force alignment enumeration
+ * (oracle/brute_force.py), (b) torch autograd through an independent log-space alpha
+ * recursion (oracle/torch_check.py) and (c) the PUBLISHED known-answer vectors of the
+ * third-party algorithm — the warp-transducer unit-test cases torchaudio's own tests reuse
+ * to pin rnnt_loss (tests/golden/published_transducer_kat.json: costs and gradients,
+ * reproduced to 3e-7; third-party published data, transcribed, not reference-held).
+ * torchaudio itself cannot be run here: "parity unpinned" against torchaudio itself stands.
  * The JOINT half IS pinned: the .npz files under tests/golden hold logits and autograd gradients produced
  * by importing the reference's own rnnt.joint.JointNetwork (tests/golden/make_golden.py).
  *
