@@ -4,23 +4,27 @@
 // rnnt/model.py:32-41: the loss gradient w.r.t. logits (torchaudio),
 // joint_ln's backward and the tanh / broadcast-add backward of rnnt/joint.py:32-39.
 //
-// The gradient w.r.t. logits, G, is never stored.  Both GEMMs regenerate it on the fly
-// from the materialised logits and the 16-byte per-cell CellCoef:
+// The gradient w.r.t. logits, G, is produced ONCE from the materialised logits and the 16-byte
+// per-cell CellCoef, in place of the logits (k_dhidden_gen does it inside the dHidden GEMM; k_make_g
+// on the fallback route):
 //      G[c,v] = exp2(logit[c,v]*log2e + c1[c]) - (v==blank)*sb[c] - (v==y[c])*se[c]
 //
-//  k_dhidden  dHidden[c,:] = G[c,:] @ W          (M = cells, K = V, N = H)
-//             then dPre = dHidden * (1 - tanh^2), reduced in the epilogue over the 16 u of
-//             the tile (-> dEnc partial) and over its 8 t (-> dPred partial); deterministic
-//             partial slabs, summed by k_reduce_*.
-//  k_dw       dW[v,h] = sum_c G[c,v] * hidden[c,h]   (M = V, N = H, K = cells, split-K)
-//             hidden is recomputed from enc/pred (tanh in registers); db is the in-lane row
-//             sum of the same G fragments.
+//  k_dhidden_gen  dHidden[c, 0:512] = G[c,:] @ W[:, 0:512]   (M = cells, K = V, N = H), G stored in
+//             place; dPre = dHidden * (1 - tanh^2) reduced in the epilogue over the tile's u
+//             (-> dEnc partial slab) and over its t (-> dPred partial slab); deterministic
+//             partial slabs, summed by k_reduce_*.  Tiles 8 t x 16 u or 16 t x 8 u (short targets).
+//  k_dhidden  the same product for the columns of H beyond 512 (the reference's joint is 1024 wide)
+//             and for shapes k_dhidden_gen does not take: persistent independent waves.
+//  k_dw       dW[v,h] = sum_c G[c,v] * hidden[c,h]   (M = V, N = H, K = cells, split-K); hidden is
+//             the tensor the forward kernel stored; db is the in-lane row sum of the same G
+//             fragments.  K walks the live cells only (contiguous ranges, or a device-built list of
+//             live 16-row granules on ragged batches).
 //
 // Like the forward kernel these feed v_mfma_f32_32x32x2_f32 straight from registers
 // (one VGPR per operand, 64 matrix-pipe cycles per instruction): no LDS staging in the
 // main loops.  A lane's 16-byte load supplies either 4 k-steps (k contiguous in memory:
-// logits for k_dhidden) or 4 interleaved tiles (m/n contiguous in memory: W rows, logits
-// for k_dw, enc/pred), so every global access is a full 16 B per lane.
+// G for the dHidden kernels) or 4 interleaved tiles (m/n contiguous in memory: W rows, G and
+// hidden for k_dw), so every global access is a full 16 B per lane.
 #include "common.hpp"
 #include "kernels.hpp"
 
