@@ -250,6 +250,8 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         if (fuse_hid) {  // only the zero padding rows the dW GEMM walks past the last cell
             const size_t cells = (size_t)B * T * U1;
             (void)hipMemsetAsync(g.hidden + cells * H, 0, (L.rows_pad + 16 - cells) * H * 4, st);
+            // and the dead cells next to lattice cells (the forward writes lattice cells only)
+            launch_zero_dead_hidden(g.hidden, logit_lens, target_lens, B, T, U1, H, st);
         } else {
             launch_make_hidden(g, st);
         }

@@ -542,8 +542,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+    // the hidden rows of the tile end with the utterance: rows t >= T would be the NEXT utterance's
+    // cells, which may be unwritten (the forward produces lattice cells only) — out of range, they read 0
+    const long rows_utt = (long)(T - t0) * U1 - u0;
+    const long hspan = span_rows < rows_utt ? span_rows : rows_utt;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.hidden + cell0 * H), 0, (int)(span_rows * H * 4), 0x00020000);
+        (void *)(a.hidden + cell0 * H), 0, (int)(hspan * H * 4), 0x00020000);
     const unsigned hvoff[2] = {colok[0] ? (unsigned)(((4 * half) * H + colg[0]) * 4) : 0xfffffff0u,
                                colok[1] ? (unsigned)(((4 * half) * H + colg[1]) * 4) : 0xfffffff0u};
     auto t_of = [&](int mt, int rh, int r7) { return (2 * wm + mt) * TPM + (BU == 16 ? rh : 2 * rh + (r7 >> 2)); };  // t row inside the tile

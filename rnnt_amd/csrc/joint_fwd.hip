@@ -87,6 +87,45 @@ __global__ __launch_bounds__(256) void k_copy_enc(const float *__restrict__ enc,
     dst[idx] = enc[(long)b * sb + (long)t * st_ + (long)h * sh];
 }
 
+// The forward produces hidden only for lattice cells.  The backward GEMMs also touch a few dead cells
+// — they multiply them by exact zeros (G == 0 there), so the rows only have to be finite: the cells
+// that share a dHidden tile (<= 16 t x 16 u) or a 16-row dW granule with a lattice cell.  Zeroed
+// here: for t < T_b the cells u in (U_b, U_b+16] and the last 16 of the row (the granule of the next
+// row's first cell reaches back into them); every cell of the 16 time steps after T_b; the last 16
+// cells of the utterance (the granule of the NEXT utterance's first cell reaches back into them).
+// A batch of full-length utterances has no such cell and the kernel writes nothing.  grid (T, B).
+__global__ __launch_bounds__(256) void k_zero_dead_hidden(float *__restrict__ hidden,
+                                                          const int32_t *__restrict__ logit_lens,
+                                                          const int32_t *__restrict__ target_lens,
+                                                          int B, int T, int U1, int H)
+{
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int Tb = len_t(logit_lens, b, T), Ub = len_u(target_lens, b, U1);
+    const int tail0 = T * U1 - 16;  // first of the utterance's last 16 cells
+    if (t >= Tb + 16 && (t + 1) * U1 <= tail0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    float *row0 = hidden + ((long)b * T + t) * U1 * H;
+    auto zero_row = [&](int u) {
+        for (int h = lane * 4; h < H; h += 256) *(f32x4 *)(row0 + (long)u * H + h) = z;
+    };
+    if (t < Tb) {
+        const int e1 = min(U1 - 1, Ub + 16);                  // (U_b, U_b + 16]
+        for (int u = Ub + 1 + wave; u <= e1; u += 4) zero_row(u);
+        for (int u = max(e1 + 1, U1 - 16) + wave; u < U1; u += 4) zero_row(u);  // the row's last 16
+    } else if (t < Tb + 16) {
+        for (int u = wave; u < U1; u += 4) zero_row(u);
+    } else {
+        for (int u = max(0, tail0 - t * U1) + wave; u < U1; u += 4) zero_row(u);
+    }
+}
+
+void launch_zero_dead_hidden(float *hidden, const int32_t *logit_lens, const int32_t *target_lens, int B, int T,
+                             int U1, int H, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_zero_dead_hidden, dim3(T, B), dim3(256), 0, st, hidden, logit_lens, target_lens, B, T, U1, H);
+}
+
 void launch_copy_enc(const float *enc, long sb, long st_, long sh, float *dst, int B, int T, int H,
                      hipStream_t st)
 {
@@ -396,6 +435,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     float2(*s_run2)[FWD_THREADS] = (float2(*)[FWD_THREADS])(smem + RING);
     float(*s_m)[FWD_ROWS] = (float(*)[FWD_ROWS])(smem + RING + 16 * FWD_THREADS * 8);
     float(*s_s)[FWD_ROWS] = s_m + 2;
+    int *s_nat = (int *)(s_s + 2);  // natural row (t*U1 + u) of the tile's compact rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: M0 of the DMAs, no per-use readfirstlane
@@ -405,30 +445,42 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     const int m0 = bx_ * FWD_ROWS;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int Tb = WITH_LOSS ? len_t(a.logit_lens, b, a.T) : T;
-    const int ncell = Tb * U1;
+    // Rows of the GEMM = the utterance's LIVE cells only, in (t, u <= U_b) order: compact index m is
+    // cell (t = m / W1, u = m % W1), W1 = U_b + 1 live columns, stored at its natural row t*U1 + u of
+    // the [cells] buffers.  A ragged batch costs its live cells; a full one (W1 == U1) is unchanged.
+    const int W1 = WITH_LOSS ? len_u(a.target_lens, b, a.U1) + 1 : U1;
+    const int ncell = Tb * W1;
     // Two workgroups share every SIMD of the CU.  A wave in one of its short non-MFMA phases (hidden
     // production, pass epilogue, finalisation) issues at priority 1, a wave in its main loop at 0: the
     // partner's MFMA stream needs one issue slot per 64 cycles and is not slowed, while the phase that
     // used to wait behind it (the SIMD arbitrates oldest-first at equal priority) overlaps it
     // (cfg2: 51.1 -> 50.3 ms).
     __builtin_amdgcn_s_setprio(1);
+    if (tid < FWD_ROWS) {  // one division per row and tile, shared through LDS by the pass epilogues
+        const int c = min(m0 + tid, ncell > 0 ? ncell - 1 : 0);
+        const int ct = c / W1;
+        s_nat[tid] = ct * U1 + (c - ct * W1);
+    }
+    if (!MAKE_HID) __syncthreads();
     if (MAKE_HID) {
         // hidden = tanh(enc + pred) for this tile's cells, produced here instead of by a separate
         // 13 GB pass (k_make_hidden): ~1 % of the tile's time, and the main loop's loads of it hit
-        // L2.  EVERY cell of the utterance gets a finite row, also past its length: the backward
-        // GEMMs multiply those rows by exact zeros.
+        // L2.  Only lattice cells are produced; the dead cells the backward GEMMs can still touch
+        // (they multiply them by exact zeros, so the rows must be finite) are zeroed by
+        // k_zero_dead_hidden.
         // Wave w takes rows w, w+8, ...; a lane takes 4 consecutive h.  Loads are batched ahead of
         // the first tanh so a tile pays a few memory round trips, not one per row: when the tile
         // spans at most two time steps (U1 >= 127) its two enc rows are loaded once and all 16 pred
         // rows of the wave are in flight together (one round trip per 256 columns); otherwise
         // batches of 8 (enc, pred) row pairs.
-        const int nrow = T * U1 - m0 < FWD_ROWS ? T * U1 - m0 : FWD_ROWS;
-        float *hid = (float *)a.hidden + ((long)b * T * U1 + m0) * H;
+        const int nrow = ncell - m0 < FWD_ROWS ? ncell - m0 : FWD_ROWS;  // <= 0: no live cell in this tile
+        float *hidb = (float *)a.hidden + (long)b * T * U1 * H;
         const float *encb = a.enc + (long)b * a.enc_sb, *predb = a.pred + (long)b * U1 * H;
         constexpr int NW = FWD_THREADS / 64, RPW = FWD_ROWS / NW;
-        const int t_first = m0 / U1;
-        const int cut = (t_first + 1) * U1 - m0;  // tile rows >= cut belong to time step t_first + 1
-        if ((m0 + nrow - 1) / U1 <= t_first + 1) {
+        const int t_first = m0 / W1;
+        const int cut = (t_first + 1) * W1 - m0;  // tile rows >= cut belong to time step t_first + 1
+        if (nrow <= 0) {
+        } else if ((m0 + nrow - 1) / W1 <= t_first + 1) {
             const int t_second = t_first + 1 < T ? t_first + 1 : t_first;
             for (int h = (tid & 63) * 4; h < H; h += 256) {
                 const f32x4 e0 = *(const f32x4 *)(encb + (long)t_first * a.enc_st + h);
@@ -438,17 +490,18 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                 for (int i = 0; i < RPW; ++i) {
                     const int r0 = wave + i * NW;
                     const int r = r0 < nrow ? r0 : nrow - 1;  // clamped: loads stay unconditional
-                    const int u = m0 + r - (r >= cut ? t_first + 1 : t_first) * U1;
+                    const int u = m0 + r - (r >= cut ? t_first + 1 : t_first) * W1;
                     p[i] = *(const f32x4 *)(predb + (long)u * H + h);
                 }
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) {
                     const int r = wave + i * NW;
                     const f32x4 e = r >= cut ? e1 : e0;  // wave-uniform
+                    const int tr = r >= cut ? t_first + 1 : t_first;
                     f32x4 o;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[q] + p[i][q]);
-                    if (r < nrow) *(f32x4 *)(hid + (long)r * H + h) = o;
+                    if (r < nrow) *(f32x4 *)(hidb + ((long)tr * U1 + (m0 + r - tr * W1)) * H + h) = o;
                 }
             }
         } else {
@@ -460,17 +513,19 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                     for (int i = 0; i < BATCH; ++i) {
                         const int r = wave + (rb + i) * NW;
                         const int c = m0 + (r < nrow ? r : nrow - 1);
-                        const int t = c / U1, u = c - t * U1;
+                        const int t = c / W1, u = c - t * W1;
                         e[i] = *(const f32x4 *)(encb + (long)t * a.enc_st + h);
                         p[i] = *(const f32x4 *)(predb + (long)u * H + h);
                     }
 #pragma unroll
                     for (int i = 0; i < BATCH; ++i) {
                         const int r = wave + (rb + i) * NW;
+                        const int c = m0 + r;
+                        const int t = c / W1, u = c - t * W1;
                         f32x4 o;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[i][q] + p[i][q]);
-                        if (r < nrow) *(f32x4 *)(hid + (long)r * H + h) = o;
+                        if (r < nrow) *(f32x4 *)(hidb + ((long)t * U1 + u) * H + h) = o;
                     }
                 }
             }
@@ -503,24 +558,17 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
 
     // this lane's A row: cell -> (t,u) -> 16-byte slices of enc / pred
     const int crow = min(m0 + wm * 32 + i, ncell - 1);
-    const int trow = crow / U1, urow = crow - trow * U1;
+    const int trow = crow / W1, urow = crow - trow * W1;
     // fused path: A comes from the hidden buffer k_make_hidden filled (the backward GEMMs need
     // it anyway), so the loop carries no tanh; the plain joint computes tanh in-loop
-    const float *erow = USE_HID ? a.hidden + ((long)b * T * U1 + crow) * H + 4 * half
+    const float *erow = USE_HID ? a.hidden + ((long)b * T * U1 + (long)trow * U1 + urow) * H + 4 * half
                                   : a.enc + (long)b * a.enc_sb + (long)trow * a.enc_st + 4 * half;
     const float *prow = a.pred + ((long)b * U1 + urow) * H + 4 * half;
-    // Ragged batches: a wave whose 32 rows all lie outside the lattice (u > U_b, or past the live
-    // cells of the tile) has nothing to compute — its logits are never read (k_dhidden_gen loads live
-    // rows only and zero-fills G itself).  The default main loop has no barrier, so such a wave simply
-    // skips it (and its epilogue) and its SIMD goes to the co-resident workgroup; the workgroup-wide
-    // barriers of the finalisation are outside the skipped region.
+    // The last tile of an utterance: a wave whose 32 rows all lie past the live cells has nothing to
+    // compute.  The default main loop has no barrier, so such a wave simply skips it (and its
+    // epilogue); the workgroup-wide barriers of the finalisation are outside the skipped region.
     bool wave_dead = false;
-#ifndef RNNT_NO_WAVESKIP
-    if (WITH_LOSS && BREG) {
-        const int myrow = m0 + wm * 32 + i;
-        wave_dead = __all(myrow >= ncell || urow > Ub);
-    }
-#endif
+    if (WITH_LOSS && BREG) wave_dead = m0 + wm * 32 >= ncell;
     const int HK = (H + 7) / 8, NG = (V + 127) / 128;
     const long wstride = (long)NG * 256;  // float4 per 8-wide k chunk
     const int npass = (NG + 3) / 4;
@@ -559,7 +607,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
             const int rowl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int c = m0 + rowl;
             const bool rv = c < ncell;
-            float *lrow = a.logits + ((long)b * T * U1 + c) * V;
+            float *lrow = a.logits + ((long)b * T * U1 + s_nat[rowl]) * V;  // compact -> natural row
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 if (rv && cok[g]) {
@@ -624,8 +672,8 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
         __syncthreads();  // also drains this workgroup's logits stores (vmcnt(0))
         if (tid < FWD_ROWS) {
             const int c = m0 + tid;
-            const int t = c / U1, u = c - t * U1;
-            if (c < ncell && u <= Ub) {  // cells past U_b are no lattice cells: nothing reads their slots
+            const int t = c / W1, u = c - t * W1;
+            if (c < ncell) {
                 const float ma = s_m[0][tid], mb = s_m[1][tid];
                 const float m = fmaxf(ma, mb);
                 const float ea = (ma == RNNT_NEG_INF) ? 0.f : __expf(ma - m);
@@ -633,7 +681,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                 const float den = m + logf(s_s[0][tid] * ea + s_s[1][tid] * eb);
                 // the two logits the lattice needs were stored by this workgroup a moment ago:
                 // read them back from L2 (agent-scope loads bypass the CU's vector L1)
-                const float *lrow = a.logits + ((long)b * T * U1 + c) * V;
+                const float *lrow = a.logits + ((long)b * T * U1 + (long)t * U1 + u) * V;
                 const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
                 const int y = (u < Ub) ? a.targets[(long)b * (U1 - 1) + u] : -1;
@@ -650,7 +698,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     STAMP(6);
 }
 
-#define FWD_SMEM(BREG) ((BREG ? 0 : FWD_NBUF * FWD_BCHUNK * 16) + 16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4)
+#define FWD_SMEM(BREG) ((BREG ? 0 : FWD_NBUF * FWD_BCHUNK * 16) + 16 * FWD_THREADS * 8 + 4 * FWD_ROWS * 4 + FWD_ROWS * 4)
 
 // one workgroup per tile, grid (tiles per utterance, B)
 template <bool WITH_LOSS, bool USE_HID, bool PAIRS = false, bool MAKE_HID = false, bool BREG = false>

@@ -42,6 +42,8 @@ size_t wpack_floats(int H, int V);
 void launch_pack_w_fwd(const float *W, float *wpack, int H, int V, hipStream_t st);
 void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st);
 int fwd_occupancy(int with_loss);
+void launch_zero_dead_hidden(float *hidden, const int32_t *logit_lens, const int32_t *target_lens, int B, int T,
+                             int U1, int H, hipStream_t st);
 void launch_copy_enc(const float *enc, long sb, long st_, long sh, float *dst, int B, int T, int H,
                      hipStream_t st);
 

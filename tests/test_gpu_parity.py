@@ -150,11 +150,16 @@ def test_poisoned_workspace_does_not_leak(amd, pattern):
         ws.view(torch.int32)[: ws.numel() // 4].fill_(pattern - (1 << 32) if pattern >= (1 << 31) else pattern)
 
     rng = np.random.default_rng(3)
+    # (the wide lattices: dead stretches longer than a dW granule / a dHidden tile, so only the dead
+    # cells NEXT to lattice cells are zeroed by k_zero_dead_hidden and the rest keeps the poison)
     for dtype, (B, T, U, H, V) in (("fp32", (3, 41, 13, 136, 68)), ("fp32", (2, 30, 9, 640, 64)),
-                                   ("bf16", (3, 41, 13, 128, 128))):
+                                   ("bf16", (3, 41, 13, 128, 128)), ("fp32", (3, 61, 70, 64, 96)),
+                                   ("fp32", (3, 50, 100, 32, 36))):
         d = make_inputs(B, T, U, H, V, seed=pattern & 0xffff)
         d["logit_lens"] = np.array(([T, 7, 23] if B == 3 else [11, T]), dtype=np.int32)
         d["target_lens"] = np.array(([4, U, 0] if B == 3 else [U, 2]), dtype=np.int32)
+        if U >= 70:
+            d["target_lens"] = np.array([U, 9, 33], dtype=np.int32)
         _run_fused(amd, d, dtype=dtype)  # sizes the workspace
         poison()
         r = _run_fused(amd, d, dtype=dtype)

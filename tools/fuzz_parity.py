@@ -12,7 +12,15 @@ from helpers import (make_inputs, oracle_fused, oracle_fused_bf16, assert_close_
                      BF16_LOSS_RTOL, BF16_GRAD_RTOL)
 
 
+def poison_workspaces():
+    """Fill every cached engine workspace with signalling NaNs: the workspace is scratch, nothing a
+    kernel does not write itself may reach a result."""
+    for ws in amd.engine._workspaces.values():
+        ws.view(torch.int32)[: ws.numel() // 4].fill_(0x7FA00000)
+
+
 def run(d, dtype):
+    poison_workspaces()
     g = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
     enc = g["enc"].requires_grad_(True); pred = g["pred"].requires_grad_(True)
     W = g["W"].requires_grad_(True); bias = g["bias"].requires_grad_(True)
