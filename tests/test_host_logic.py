@@ -102,3 +102,50 @@ def test_padding_helper_keeps_zero_probability_columns():
     e, p, Wp, bp, H, V = _pad_hv(enc, pred, W, b)
     assert e.shape[-1] == 8 and Wp.shape == (8, 8) and (H, V) == (6, 5)
     assert (Wp[5:] == 0).all() and (Wp[:, 6:] == 0).all() and (bp[5:] < -1e29).all()
+
+
+def test_conv_predictor_mirrors_reference_interface_and_has_no_cpu_path(golden_dir):
+    """rnnt_amd.ConvPredictor: the reference's constructor and state-dict keys
+    (rnnt/predictor.py:189-209: embedding, input_layer_norm, conv1.conv, conv2.conv, linear,
+    output_layer_norm); CPU tensors fail loudly (no fallback)."""
+    z = np.load(os.path.join(golden_dir, "predictor_small.npz"))
+    S, O, E, B, U1 = (int(v) for v in z["dims"])
+    m = rnnt_amd.ConvPredictor(S, O, E, dropout=0.3)
+    ref_keys = sorted(k[4:].replace("__", ".") for k in z.files if k.startswith("sd__"))
+    assert sorted(m.state_dict().keys()) == ref_keys
+    assert m.conv1.conv.weight.shape == (E, E, 3) and m.conv2.conv.weight.shape == (E, E, 5)
+    m.load_state_dict({k: torch.from_numpy(z["sd__" + k.replace(".", "__")]) for k in ref_keys})
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.from_numpy(z["ids"]))
+    with pytest.raises(NotImplementedError):
+        from rnnt_amd.predictor import CausalConv1d
+        CausalConv1d(4, 4, 3, stride=2, dilation=1)
+
+
+def test_optim_host_logic():
+    """clip_grad_norm_ on the reference's exhausted generator (rnnt/train.py:95,104,136) is a no-op
+    returning 0; AdamW validates hyper-parameters and refuses CPU parameters (no fallback)."""
+    p = torch.nn.Parameter(torch.ones(4))
+    p.grad = torch.ones(4) * 3
+    gen = (q for q in [p])
+    list(gen)
+    assert float(rnnt_amd.optim.clip_grad_norm_(gen, 0.1)) == 0.0 and torch.equal(p.grad, torch.ones(4) * 3)
+    assert float(rnnt_amd.optim.clip_grad_norm_([torch.nn.Parameter(torch.ones(2))], 1.0)) == 0.0  # no .grad
+    with pytest.raises(ValueError):
+        rnnt_amd.optim.AdamW([p], lr=-1.0)
+    opt = rnnt_amd.optim.AdamW([p], lr=3e-4, betas=(0.95, 0.9999), eps=1e-8, weight_decay=0.01)
+    assert opt.defaults["betas"] == (0.95, 0.9999)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        opt.step()
+
+
+def test_projected_joint_single_forward_stays_plain_torch_on_cpu(golden_dir):
+    """The export / decode path (rnnt/joint.py:44-55) with audio_ln / text_ln runs on CPU tensors
+    through torch's own Linear (the engine's projection kernels only take HIP tensors)."""
+    z = np.load(os.path.join(golden_dir, "joint_proj.npz"))
+    Fa, Ft, H, V = (int(x) for x in z["ctor"])
+    m = rnnt_amd.JointNetwork(Fa, Ft, H, V)
+    m.load_state_dict({k[4:].replace("__", "."): torch.from_numpy(z[k]) for k in z.files if k.startswith("sd__")})
+    a, t = torch.from_numpy(z["audio"]), torch.from_numpy(z["text"])
+    out = m.single_forward(a[:, 1, :], t[:, 2, :]).detach().numpy()
+    np.testing.assert_allclose(out, z["logits_f32"][:, 1, 2, :], rtol=0, atol=2e-5)
