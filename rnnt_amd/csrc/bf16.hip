@@ -157,7 +157,7 @@ void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
     // hidden is produced by the forward kernel's tiles; only the zero padding rows past the last cell
     // (the dW DMA ring walks them) are written here
     const long cells = (long)a.B * a.T * a.U1;
-    (void)hipMemsetAsync(a.hidden + cells * a.H, 0, (size_t)(a.rows_alloc - cells) * a.H * 2, st);
+    launch_fill32(a.hidden + cells * a.H, 0u, (size_t)(a.rows_alloc - cells) * a.H * 2, st);
     const long nf = (long)(bf16_wpack_fwd_bytes(a.H, a.V) / 16);
     hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W,
                        (u32x4 *)a.wpack_fwd, a.H, a.V, a.H / 32, nf);
@@ -649,7 +649,7 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
 {
     const long cells = (long)a.B * a.T * a.U1;
     // zero padding rows: G of rows k_dw_bf16 walks past the last cell, and the "dead row" source
-    (void)hipMemsetAsync(a.logits + cells * a.V, 0, (size_t)(a.rows_alloc - cells) * a.V * 2, st);
+    launch_fill32(a.logits + cells * a.V, 0u, (size_t)(a.rows_alloc - cells) * a.V * 2, st);
     dim3 grid(a.n_ublk, (a.T + BG_BT - 1) / BG_BT, a.B);
     hipLaunchKernelGGL(k_dhidden_bf16<true>, grid, dim3(512), 0, st, a, 0);
     for (int hp = 1; hp * 512 < a.H; ++hp) hipLaunchKernelGGL(k_dhidden_bf16<false>, grid, dim3(512), 0, st, a, hp);

@@ -118,6 +118,50 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->total = o;
 }
 
+}  // namespace
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_fill32(unsigned *__restrict__ p, unsigned value, size_t n_words, int vec)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {  // 16-byte aligned, whole uint4s
+        if (i < n_words / 4) ((u32x4 *)p)[i] = u32x4{value, value, value, value};
+    } else if (i < n_words) {
+        p[i] = value;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_copy32(unsigned *__restrict__ d, const unsigned *__restrict__ s, size_t n_words, int vec)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec) {
+        if (i < n_words / 4) ((u32x4 *)d)[i] = ((const u32x4 *)s)[i];
+    } else if (i < n_words) {
+        d[i] = s[i];
+    }
+}
+
+void launch_fill32(void *p, unsigned value, size_t bytes, hipStream_t st)
+{
+    const size_t n = bytes / 4;
+    if (!n) return;
+    const int vec = ((uintptr_t)p % 16 == 0) && (n % 4 == 0);
+    const size_t thr = vec ? n / 4 : n;
+    hipLaunchKernelGGL(k_fill32, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, (unsigned *)p, value, n, vec);
+}
+
+void launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    const size_t n = bytes / 4;
+    if (!n) return;
+    const int vec = ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0) && (n % 4 == 0);
+    const size_t thr = vec ? n / 4 : n;
+    hipLaunchKernelGGL(k_copy32, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, (unsigned *)dst, (const unsigned *)src, n, vec);
+}
+
+namespace {
+
 int launch_status(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -249,7 +293,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     if (stages & ST_PROD) {
         if (fuse_hid) {  // only the zero padding rows the dW GEMM walks past the last cell
             const size_t cells = (size_t)B * T * U1;
-            (void)hipMemsetAsync(g.hidden + cells * H, 0, (L.rows_pad + 16 - cells) * H * 4, st);
+            launch_fill32(g.hidden + cells * H, 0u, (L.rows_pad + 16 - cells) * H * 4, st);
             // and the dead cells next to lattice cells (the forward writes lattice cells only)
             launch_zero_dead_hidden(g.hidden, logit_lens, target_lens, B, T, U1, H, st);
         } else {
@@ -396,13 +440,13 @@ int rnnt_engine_joint_bwd(const void *enc, const int64_t enc_strides[3], const v
     // every utterance at full length: the upstream gradient is dense (zero where the caller's loss
     // ignored a cell); the length arrays the kernels read live in the (unused) coefficient region
     int32_t *ll = (int32_t *)(ws + L.coef), *tl = ll + B;
-    (void)hipMemsetD32Async((hipDeviceptr_t)ll, T, B, st);
-    (void)hipMemsetD32Async((hipDeviceptr_t)tl, U1 - 1, B, st);
+    launch_fill32(ll, (unsigned)T, (size_t)B * 4, st);
+    launch_fill32(tl, (unsigned)(U1 - 1), (size_t)B * 4, st);
     // G with the zero padding rows the dW GEMM walks past the last cell
     const size_t cells = (size_t)B * T * U1;
     float *G = (float *)(ws + L.logits);
-    (void)hipMemcpyAsync(G, grad_logits, cells * V * 4, hipMemcpyDeviceToDevice, st);
-    (void)hipMemsetAsync(G + cells * V, 0, (L.rows_pad + 16 - cells) * V * 4, st);
+    launch_copy_bytes(G, grad_logits, cells * V * 4, st);
+    launch_fill32(G + cells * V, 0u, (L.rows_pad + 16 - cells) * V * 4, st);
     JointBwdArgs g;
     memset(&g, 0, sizeof g);
     g.enc = encp; g.enc_sb = esb; g.enc_st = est; g.pred = (const float *)pred; g.W = (const float *)W;

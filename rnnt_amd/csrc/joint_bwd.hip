@@ -715,7 +715,7 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
     if (a.flags & 16) {  // fused G producer (engine decides: dhidden_gen_ok)
         // zero the padding rows k_dw may touch (k_make_g used to)
         const long cells = (long)a.B * a.T * a.U1;
-        (void)hipMemsetAsync((float *)a.logits + cells * a.V, 0, (size_t)(a.rows_pad + 16 - cells) * a.V * 4, st);
+        launch_fill32((float *)a.logits + cells * a.V, 0u, (size_t)(a.rows_pad + 16 - cells) * a.V * 4, st);
         if (a.gen_bu == 8) {
             dim3 grid((a.U1 + 7) / 8, (a.T + 15) / 16, a.B);
             hipLaunchKernelGGL(k_dhidden_gen<8>, grid, dim3(256), 0, st, a);
@@ -727,7 +727,7 @@ void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
         // H > 512 (the reference's joint is 1024 wide): G now stands in place of the logits; the
         // remaining column blocks are plain G x W products for the persistent kernel
     }
-    (void)hipMemsetAsync(a.counter, 0, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
+    launch_fill32(a.counter, 0u, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
     if (a.gen_bu == 8) hipLaunchKernelGGL(k_dhidden<8>, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
     else hipLaunchKernelGGL(k_dhidden<16>, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
 }

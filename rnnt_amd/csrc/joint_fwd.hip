@@ -739,7 +739,7 @@ void launch_joint_fwd(const JointFwdArgs &a, hipStream_t st)
         if (pairs && !(a.flags & 128)) {
             const long ntot = (long)tiles * a.B;
             if (a.counter && !(a.flags & 256) && ntot < 0x7fffffffL) {
-                (void)hipMemsetAsync(a.counter, 0, 4, st);
+                launch_fill32(a.counter, 0u, 4, st);
                 const int nwg = (int)(ntot < 2L * a.n_cu ? ntot : 2L * a.n_cu);
                 if (a.make_hidden)
                     hipLaunchKernelGGL((k_joint_fwd_persist<true, true, true, true, true>), dim3(nwg), block, 0, st, a, tiles, (int)ntot);

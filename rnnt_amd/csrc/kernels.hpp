@@ -4,6 +4,12 @@
 
 // ---- engine.hip: sets the thread-local error message, returns `code`
 int engine_fail(int code, const char *fmt, ...);
+// fills / copies as ordinary kernels on the caller's stream (in place of hipMemsetAsync / hipMemcpyAsync):
+// a captured call is then a chain of kernel nodes only — with memset nodes in the chain, replays of a
+// whole-pipeline HIP graph ran kernels against stale counters (ROCm 7.2; tests/test_gpu_parity.py::
+// test_fused_call_is_hip_graph_capturable).  `bytes` and `p` multiples of 4.
+void launch_fill32(void *p, unsigned value, size_t bytes, hipStream_t st);
+void launch_copy_bytes(void *dst, const void *src, size_t bytes, hipStream_t st);
 
 // ---- lattice.hip
 void launch_logsoftmax_gather(const float *logits, const int32_t *targets,

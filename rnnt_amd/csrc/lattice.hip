@@ -450,7 +450,7 @@ void launch_lattice(const float *lpb_s, const float *lpe_s, double *alpha_s, dou
     const int NW = (U1 + 63) / 64;
     const size_t mbox = (size_t)(NW - 1) * D * 12;  // chain mailboxes: 8 B value + 4 B tag per boundary and step
     if (mbox <= 64 * 1024) {
-        if (NW > 1) (void)hipMemsetAsync(err, 0, 4, st);  // one wave: no mailbox, no spin
+        if (NW > 1) launch_fill32(err, 0u, 4, st);  // one wave: no mailbox, no spin
         hipLaunchKernelGGL(k_lattice_chain, dim3(B, 2), dim3(64 * NW), (mbox + 15) / 16 * 16, st, lpb_s, lpe_s, alpha_s,
                            beta_s, logit_lens, target_lens, costs, U1, D, err);
         if (NW > 1) hipLaunchKernelGGL(k_lattice_status, dim3(1), dim3(64), 0, st, err, costs, B);

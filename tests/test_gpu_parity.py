@@ -773,3 +773,66 @@ def test_fullsize_config4_softmax_shift_invariance(amd):
         assert np.abs(r0[k]).max() > 0
     assert abs(r0["grad_bias"].sum()) < 1e-3 * np.abs(r0["grad_bias"]).sum()
     assert (r0["costs"] > 0).all()
+
+
+def _fused_outs(amd, g, outs=None, dtype="fp32"):
+    V = g["W"].shape[0]
+    return amd.engine.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"],
+                                         g["target_lens"], V - 1, 0.25, outs=outs, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype,shape", [("fp32", (3, 40, 12, 256, 512)), ("fp32", (2, 30, 9, 1024, 260)),
+                                         ("fp32", (2, 30, 9, 1024, 256)), ("bf16", (3, 40, 12, 256, 512)),
+                                         ("bf16", (2, 30, 9, 1024, 256))])
+def test_fused_call_is_hip_graph_capturable(amd, dtype, shape):
+    """The C-ABI call enqueues kernels and async memsets on the caller's stream and nothing else (no
+    allocation, no synchronisation, no host read-back): it can be captured into a HIP graph and
+    replayed.  The replay reads its inputs at replay time — new contents in the same buffers give the
+    new answer, bit for bit what the eager call gives."""
+    B, T, U, H, V = shape
+    d1, d2 = make_inputs(B, T, U, H, V, seed=501), make_inputs(B, T, U, H, V, seed=502)
+    g = _dev(d1)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        outs = tuple(torch.empty_like(o) for o in _fused_outs(amd, g, dtype=dtype))  # warm-up: sizes the (device, stream) workspace
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            _fused_outs(amd, g, outs=outs, dtype=dtype)
+    torch.cuda.current_stream().wait_stream(s)
+    for d in (d2, d1):
+        for k, v in d.items():
+            g[k].copy_(torch.from_numpy(v))
+        for o in outs:
+            o.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [o.clone() for o in outs]
+        want = _fused_outs(amd, g, dtype=dtype)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(got, want):
+            assert torch.equal(a_, b_)
+        ref = oracle_fused_bf16(d) if dtype == "bf16" else oracle_fused(d)
+        assert_close_loss("costs", got[0].cpu().numpy(), ref["costs"], rtol=BF16_LOSS_RTOL if dtype == "bf16" else LOSS_RTOL)
+
+
+def test_two_streams_do_not_share_scratch(amd):
+    """Two streams of one device, different inputs, enqueued back to back with no synchronisation in
+    between: each (device, stream) has its own workspace, so both answers equal their serial runs."""
+    da, db = make_inputs(4, 120, 30, 512, 1024, seed=511), make_inputs(4, 120, 30, 512, 1024, seed=512)
+    ga, gb = _dev(da), _dev(db)
+    want_a = [o.clone() for o in _fused_outs(amd, ga)]
+    want_b = [o.clone() for o in _fused_outs(amd, gb)]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    res = {}
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            res["a"] = _fused_outs(amd, ga)
+        with torch.cuda.stream(sb):
+            res["b"] = _fused_outs(amd, gb)
+    torch.cuda.synchronize()
+    for got, want in ((res["a"], want_a), (res["b"], want_b)):
+        for x, y in zip(got, want):
+            assert torch.equal(x, y)
