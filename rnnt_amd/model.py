@@ -13,6 +13,10 @@ class RNNTModel(torch.nn.Module):
         self.predictor = predictor
         self.encoder = encoder
         self.joint = joint
+        # torchaudio's host-side length checks (max(lengths) == T / U: they synchronise).  False skips
+        # them — the kernels clamp every length into range — so that forward + backward enqueue
+        # device work only and can be captured into a HIP graph.
+        self.check_lengths = True
 
     @property
     def device(self):
@@ -35,7 +39,7 @@ class RNNTModel(torch.nn.Module):
                                      targets=input_ids.int(),
                                      logit_lengths=audio_feature_lens.int(),
                                      target_lengths=input_id_lens.int(),
-                                     blank=-1, reduction="mean")
+                                     blank=-1, reduction="mean", check_lengths=self.check_lengths)
 
     # ---- greedy decode (reference model.py:45-139); host loop, not on the engine's path
     def _predictor_is_stateful(self) -> bool:

@@ -168,3 +168,67 @@ def test_bench_nccl_path_with_one_rank():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["hipGetDeviceCount"] >= 1
     assert line["value"] > 0 and np.isfinite(line["loss"])
+
+
+def test_forward_backward_as_one_hip_graph():
+    """SURVEY §8(b) threading/streams row: everything the model call enqueues goes to the caller's
+    stream.  With the host-side length checks off (`model.check_lengths = False`; the kernels clamp)
+    forward + backward of rnnt_amd.RNNTModel — encoder stand-in, engine ConvPredictor, projections,
+    fused joint + loss, autograd — is capturable as ONE HIP graph (torch.cuda.graph), and a replay on
+    new batch contents gives the eager loss and gradients."""
+    import rnnt_amd
+
+    assert torch.cuda.is_available()
+    rnnt_amd.engine.lib()
+    device = torch.device("cuda:0")
+    torch.manual_seed(3)
+    vocab, n_mels, feats, hidden = 64, 16, 96, 256
+    model = rnnt_amd.RNNTModel(rnnt_amd.ConvPredictor(vocab, feats, 128, dropout=0.0), _Encoder(n_mels, feats),
+                               rnnt_amd.JointNetwork(feats, feats, hidden, vocab)).to(device)
+    model.train()
+    model.check_lengths = False
+    blank_idx = vocab - 1
+    b0, b1 = _batch(4, n_mels, 60, 10, vocab, seed=7), _batch(4, n_mels, 60, 10, vocab, seed=8)
+    static = {k: v.to(device) for k, v in b0.items()}
+    params = [p for p in model.parameters()]
+
+    def fwd_bwd():
+        loss = model(static["mel_features"], static["mel_feature_lens"], static["input_ids"],
+                     static["input_id_lens"], blank_idx)
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):  # warm-up on the capture stream: workspaces, autograd buffers
+            for p in params:
+                p.grad = None
+            fwd_bwd()
+        s.synchronize()
+        for p in params:
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            static_loss = fwd_bwd()
+    torch.cuda.current_stream().wait_stream(s)
+    static_grads = [p.grad for p in params]
+    assert all(g is not None for g in static_grads)
+
+    for batch in (b1, b0):
+        for k, v in batch.items():
+            static[k].copy_(v)
+        graph.replay()
+        torch.cuda.synchronize()
+        got_loss = static_loss.item()
+        got = [g.clone() for g in static_grads]
+        for p in params:
+            p.grad = None
+        want_loss = fwd_bwd().item()
+        torch.cuda.synchronize()
+        assert got_loss == want_loss
+        for (name, p), g in zip(model.named_parameters(), got):
+            assert torch.equal(g, p.grad), name
+        # the captured gradient buffers stay the graph's outputs for the next replay
+        for p, g in zip(params, static_grads):
+            p.grad = g
