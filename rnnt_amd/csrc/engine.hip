@@ -285,7 +285,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     }
     // G inside the dHidden GEMM unless the shape needs the separate pass (or flag 32 forces it)
     const bool fuse_g = dhidden_gen_ok(H, V, U1) && !(xflags & 32);
-    if (fuse_g) { g.flags |= 16; g.pred_split_col = 512; }  // k_dhidden_gen covers columns 0-511
+    if (fuse_g) { g.flags |= 16; g.pred_split_col = 512 * dhidden_gen_groups(H); }  // columns on the tile kernel (8-row dPred slabs)
 
     // hidden (A operand of all three GEMMs) is produced by the forward kernel for its own tile
     // unless flag 64 asks for the separate k_make_hidden pass

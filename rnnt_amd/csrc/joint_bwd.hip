@@ -271,8 +271,11 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #endif
 // BU = u width of the tile (16: 8 t x 16 u; 8: 16 t x 8 u, for short targets — U1 = 101 fills 7 blocks
 // of 16 with 10 % dead rows, 13 blocks of 8 with 3 %); an M tile of 32 rows is (32/BU) t rows of BU u.
-template <int BU>
-__global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
+// GEN = false (H >= 1024: further whole groups of 512 columns, `col_base` = 512, 1024, ...): the same tile,
+// schedule and epilogue on the G the GEN launch left in place of the logits — loaded, handed through the
+// exchange and multiplied as is; nothing is produced or stored but the slabs.
+template <int BU, bool GEN>
+__global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a, const int col_base)
 {
     constexpr int BT = 128 / BU;  // t rows per tile
     __shared__ __attribute__((aligned(16))) float smem[4 * 4 * 256 + 2 * 64 * 65];  // 4-slot G exchange + epilogue
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : (long)a.B * T * U1;  // else zero row
     float *lptr = (float *)a.logits + pcell * V + 4 * half;
 
+    if (!GEN && (t0 >= Tb || u0 > len_u(a.target_lens, b, a.U1))) return;  // dead tile: no slab is read
     if (t0 >= Tb) {  // workgroup-uniform: nothing to multiply, but k_dw must find zeros here
         // k_dw only walks the live rows, rounded out to 16-cell granules (k_dw_table): up to 15
         // cells past this utterance's live end, and up to 15 cells before the next utterance's
@@ -315,9 +319,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     }
     GSTAMP(0);
 
-    CellCoef cf = a.coef[pexists ? pcell : 0];
-    const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
-    const int ncol0 = wn * 256;
+    CellCoef cf;
+    cf.c1 = 0.f; cf.sb = 0.f; cf.se = 0.f; cf.y = -1;
+    if (GEN) cf = a.coef[pexists ? pcell : 0];
+    // GEN = false: the G rows of this tile's cells outside the lattice are exact zeros already
+    const bool live = GEN ? (pexists && pt < Tb && cf.c1 != RNNT_NEG_INF) : pexists;
+    const int ncol0 = col_base + wn * 256;
     const int colg[2] = {ncol0 + 4 * i, ncol0 + 128 + 4 * i};
     const bool colok[2] = {colg[0] < H, colg[1] < H};
     // columns beyond H read column 0: they feed accumulators that are never stored
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
     // two fixups touch one element of one chunk per row, so they sit behind wave-uniform tests.
     if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
     auto gen = [&](const f32x4 &x, int c8) {
+        if (!GEN) return x;
         f32x4 g;
         const int vb = 8 * c8 + 4 * half;
 #pragma unroll
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrsrc, xvoff, 32 * (c8 < VK ? c8 : VK - 1), 0));
     };
     auto gstore = [&](const f32x4 &g, int c8) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), lrsrc, svoff, 32 * c8, 0);
+        if (GEN) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), lrsrc, svoff, 32 * c8, 0);
     };
 
     f32x4 xr[4];           // raw logits of chunks c+3 .. c+6 (ring, slot = chunk & 3)
@@ -438,19 +446,27 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 mf(0, 0); cur[1][0] = wf[j & 1][1][0]; PIN();
                 mf(0, 1); cur[1][1] = wf[j & 1][1][1]; PIN();
                 mf(0, 2);
+                if (GEN) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { gn[e] = fmaf(x[e], RNNT_LOG2E, cf.c1); asm volatile("" : "+v"(gn[e])); }
+                    for (int e = 0; e < 4; ++e) { gn[e] = fmaf(x[e], RNNT_LOG2E, cf.c1); asm volatile("" : "+v"(gn[e])); }
+                } else {
+                    gn = x;
+                }
                 PIN();
                 mf(0, 3);
-                gn[0] = __builtin_amdgcn_exp2f(gn[0]); gn[1] = __builtin_amdgcn_exp2f(gn[1]);
-                asm volatile("" : "+v"(gn[0]), "+v"(gn[1]));
+                if (GEN) {
+                    gn[0] = __builtin_amdgcn_exp2f(gn[0]); gn[1] = __builtin_amdgcn_exp2f(gn[1]);
+                    asm volatile("" : "+v"(gn[0]), "+v"(gn[1]));
+                }
                 PIN();
                 mf(0, 4);
-                gn[2] = __builtin_amdgcn_exp2f(gn[2]); gn[3] = __builtin_amdgcn_exp2f(gn[3]);
-                asm volatile("" : "+v"(gn[2]), "+v"(gn[3]));
+                if (GEN) {
+                    gn[2] = __builtin_amdgcn_exp2f(gn[2]); gn[3] = __builtin_amdgcn_exp2f(gn[3]);
+                    asm volatile("" : "+v"(gn[2]), "+v"(gn[3]));
+                }
                 PIN();
                 mf(0, 5);
-                {
+                if (GEN) {
                     const unsigned dy = (unsigned)(cf.y - vbn);
                     if (__any(dy < 4u)) {
 #pragma unroll
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a)
                 }
                 PIN();
                 mf(0, 6);
-                if (cn == blank_chunk) {  // wave-uniform, one chunk in V/8
+                if (GEN && cn == blank_chunk) {  // wave-uniform, one chunk in V/8
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (vbn + e == a.blank) gn[e] -= cf.sb;
@@ -661,6 +677,8 @@ bool dhidden_gen_ok(int H, int V, int U1)
     return (V % 32) == 0 && (long)V * H * 4 < 0xffffffffL && span_rows * wide * 4 < 0x7fffffffL;
 }
 #define DG_COLS 512  // columns of H one k_dhidden_gen workgroup covers
+// column groups of 512 the tile kernel takes: the first (which produces G) and every further WHOLE one
+int dhidden_gen_groups(int H) { return H <= DG_COLS ? 1 : H / DG_COLS; }
 
 // out[b,t,:] = sum_ub slab_enc[ub][b,t,:]  (0 for t >= T_b)
 __global__ __launch_bounds__(256) void k_reduce_enc(const float *__restrict__ slab,
@@ -712,24 +730,30 @@ __global__ __launch_bounds__(256) void k_reduce_pred(const float *__restrict__ s
 
 void launch_dhidden(const JointBwdArgs &a, hipStream_t st)
 {
+    int cb0 = 0;  // first 128-column block left to the persistent kernel
     if (a.flags & 16) {  // fused G producer (engine decides: dhidden_gen_ok)
         // zero the padding rows k_dw may touch (k_make_g used to)
         const long cells = (long)a.B * a.T * a.U1;
         launch_fill32((float *)a.logits + cells * a.V, 0u, (size_t)(a.rows_pad + 16 - cells) * a.V * 4, st);
+        // H > 512 (the reference's joint is 1024 wide): G now stands in place of the logits; every
+        // further WHOLE group of 512 columns runs on the same tile kernel reading G (GEN = false), what
+        // is left (H % 512 columns: cfg4's H = 640) on the persistent kernel
+        const int n_full = dhidden_gen_groups(a.H);
         if (a.gen_bu == 8) {
             dim3 grid((a.U1 + 7) / 8, (a.T + 15) / 16, a.B);
-            hipLaunchKernelGGL(k_dhidden_gen<8>, grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_dhidden_gen<8, true>), grid, dim3(256), 0, st, a, 0);
+            for (int hp = 1; hp < n_full; ++hp) hipLaunchKernelGGL((k_dhidden_gen<8, false>), grid, dim3(256), 0, st, a, hp * DG_COLS);
         } else {
             dim3 grid((a.U1 + 15) / 16, (a.T + DG_BT - 1) / DG_BT, a.B);
-            hipLaunchKernelGGL(k_dhidden_gen<16>, grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_dhidden_gen<16, true>), grid, dim3(256), 0, st, a, 0);
+            for (int hp = 1; hp < n_full; ++hp) hipLaunchKernelGGL((k_dhidden_gen<16, false>), grid, dim3(256), 0, st, a, hp * DG_COLS);
         }
-        if (a.H <= DG_COLS) return;
-        // H > 512 (the reference's joint is 1024 wide): G now stands in place of the logits; the
-        // remaining column blocks are plain G x W products for the persistent kernel
+        cb0 = n_full * (DG_COLS / 128);
+        if (cb0 * 128 >= a.H) return;
     }
     launch_fill32(a.counter, 0u, 8 * 64, st);  // per-XCD work-item counters (64 B apart)
-    if (a.gen_bu == 8) hipLaunchKernelGGL(k_dhidden<8>, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
-    else hipLaunchKernelGGL(k_dhidden<16>, dim3(a.n_cu), dim3(512), 0, st, a, (a.flags & 16) ? DG_COLS / 128 : 0);
+    if (a.gen_bu == 8) hipLaunchKernelGGL(k_dhidden<8>, dim3(a.n_cu), dim3(512), 0, st, a, cb0);
+    else hipLaunchKernelGGL(k_dhidden<16>, dim3(a.n_cu), dim3(512), 0, st, a, cb0);
 }
 
 void launch_dhidden_reduce(const JointBwdArgs &a, hipStream_t st)

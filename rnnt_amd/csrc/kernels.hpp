@@ -89,6 +89,7 @@ void launch_dw_reduce(const JointBwdArgs &a, hipStream_t st);
 void launch_make_hidden(const JointBwdArgs &a, hipStream_t st);
 void launch_make_g(const JointBwdArgs &a, hipStream_t st);
 bool dhidden_gen_ok(int H, int V, int U1);
+int dhidden_gen_groups(int H);  // 512-column groups on the tile kernel (the rest: persistent k_dhidden)
 int dhidden_gen_bu(int T, int U1);  // 16 or 8: the tile form that pads the lattice least  // k_dhidden_gen (G produced inside the dHidden GEMM) applies
 
 // ---- bf16.hip (RNNT_DTYPE_BF16 route: bf16 GEMM operands, fp32 accumulate / logits / loss)
