@@ -123,6 +123,8 @@ class AdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if torch.is_tensor(st["step"]):  # state loaded from a torch.optim.AdamW checkpoint (util.py:7-12)
+                    st["step"] = int(st["step"].item())
                 st["step"] += 1
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])

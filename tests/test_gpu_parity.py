@@ -56,9 +56,11 @@ FUSED_SHAPES = [
     (1, 1, 0, 8, 4), (1, 1, 3, 8, 8), (2, 5, 0, 16, 8), (2, 5, 2, 16, 8), (3, 17, 8, 64, 32),
     (2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 12, 5, 128, 1024), (2, 40, 33, 72, 520),
     (2, 7, 3, 10, 7), (4, 30, 12, 520, 260), (1, 64, 40, 32, 1300),
-    # H > 512 (the reference's joint is 1024 wide): k_dhidden_gen covers columns 0-511, the
-    # persistent k_dhidden the rest (4-row t tiles: two dPred slab heights in one reduction)
+    # H > 512 (the reference's joint is 1024 wide): k_dhidden_gen covers columns 0-511 and every further
+    # whole group of 512 (reading G), the persistent k_dhidden the H % 512 rest (4-row t tiles: two
+    # dPred slab heights in one reduction)
     (3, 21, 18, 1024, 64), (2, 10, 35, 768, 160), (2, 13, 6, 640, 1024), (2, 9, 4, 516, 96),
+    (2, 19, 7, 1536, 32), (2, 11, 20, 1152, 96), (3, 33, 5, 1028, 64),
 ]
 
 

@@ -92,3 +92,42 @@ def test_adamw_rejects_what_it_cannot_do():
         rnnt_amd.optim.AdamW([q]).step()
     with pytest.raises(ValueError):
         rnnt_amd.optim.AdamW([torch.zeros(1, device="cuda", requires_grad=True)], betas=(1.0, 0.9))
+
+
+def test_optimizer_checkpoint_moves_between_torch_and_engine(tmp_path):
+    """The reference checkpoints `optimizer.state_dict()` (rnnt/util.py:7-12, train.py:204-210).  A
+    state dict written by torch.optim.AdamW loads into the engine's AdamW (torch keeps `step` as a
+    tensor) and the other way round; training continues on the same trajectory."""
+    import rnnt_amd
+    a, b = _params(5), _params(5)
+    ref = torch.optim.AdamW(a, foreach=False, fused=False, **HP)
+    opt = rnnt_amd.optim.AdamW(b, **HP)
+    for step in range(3):  # ref trains, then hands over through a file
+        _set_grads(a, 200 + step)
+        ref.step()
+    torch.save({"optimizer_state_dict": ref.state_dict(), "completed_steps": 3}, tmp_path / "ck.pt")
+    with torch.no_grad():
+        for x, y in zip(a, b):
+            y.copy_(x)
+    opt.load_state_dict(torch.load(tmp_path / "ck.pt")["optimizer_state_dict"])
+    for step in range(3, 6):
+        _set_grads(a, 200 + step)
+        _set_grads(b, 200 + step)
+        ref.step()
+        opt.step()
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=2e-6, atol=1e-7)
+    # and back: the engine's state dict into a fresh torch optimizer
+    c = _params(5)
+    with torch.no_grad():
+        for y, z in zip(b, c):
+            z.copy_(y)
+    back = torch.optim.AdamW(c, foreach=False, fused=False, **HP)
+    torch.save(opt.state_dict(), tmp_path / "ck2.pt")  # through a file: load_state_dict does not copy same-device tensors
+    back.load_state_dict(torch.load(tmp_path / "ck2.pt"))
+    for step in range(6, 8):
+        for ps in (a, b, c):
+            _set_grads(ps, 200 + step)
+        ref.step(); opt.step(); back.step()
+    for x, y, z in zip(a, b, c):
+        assert torch.allclose(x, y, rtol=3e-6, atol=1e-7) and torch.allclose(x, z, rtol=3e-6, atol=1e-7)

@@ -42,7 +42,7 @@ if __name__ == "__main__":
         bf = it >= n32
         B = int(rng.integers(1, 6)); T = int(rng.integers(1, 70)); U = int(rng.integers(0, 40))
         if bf:
-            H = int(rng.choice([128, 256, 384, 512, 640, 768, 1024])); V = 128 * int(rng.integers(1, max(2, maxv // 32) + 1))
+            H = int(rng.choice([128, 256, 384, 512, 640, 768, 1024, 1152, 1536])); V = 128 * int(rng.integers(1, max(2, maxv // 32) + 1))
         else:
             H = 4 * int(rng.integers(1, maxh + 1)); V = 4 * int(rng.integers(1, maxv + 1))
             if it % 3 == 0:  # the fused dHidden kernel needs V % 32 == 0: make a third of the cases take it
