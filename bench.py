@@ -216,11 +216,18 @@ def main():
     gp = torch.empty(Bl, U + 1, H, dtype=torch.float32, device=device)
     outs = (costs, ge, gp, gW, gb)
 
+    # transport of the one all-reduce: torch.distributed's "nccl" backend (= RCCL; default), or with
+    # BENCH_COMM=engine the C entry rnnt_engine_allreduce on a communicator of the bench's own
+    comm = None
+    if dist_on and backend == "nccl" and os.environ.get("BENCH_COMM") == "engine":
+        from rnnt_amd.parallel import RcclComm
+        comm = RcclComm(rank, world, device)
+
     def step():
         engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs,
                                   dtype=args.dtype)
         fg.set_loss(costs, scale)
-        fg.all_reduce()  # N>1: one RCCL all-reduce over xGMI of dW, db and the loss
+        fg.all_reduce(comm=comm)  # N>1: one RCCL all-reduce over xGMI of dW, db and the loss
 
     for _ in range(args.warmup):
         step()
@@ -281,6 +288,7 @@ def main():
         # what actually ran: devices the runtime sees, ranks in the RCCL communicator
         "hipGetDeviceCount": torch.cuda.device_count(),
         "rccl_ranks": dist.get_world_size() if dist_on else 0,
+        "allreduce_via": ("rnnt_engine_allreduce" if comm is not None else "torch.distributed") if dist_on else None,
     }
     flops_cell = 6.0 * H * V  # 2HV fwd + 2HV dHidden + 2HV dW per lattice cell
     cells1 = Bl * T * (U + 1)  # cells the GEMMs actually process per launch (U+1 columns)

@@ -256,6 +256,18 @@ int rnnt_engine_linear_bwd(const float *x, int64_t ldx, const float *W, const fl
                            void *stream);
 
 /*
+ * Multi-GPU step of the path (the suggested export of 8b): ONE sum all-reduce, in
+ * place, of `count` fp32 values — the flat [dW (V*H) | db (V) | loss] buffer of a batch-sharded
+ * step — on the caller's RCCL communicator (`comm` is an ncclComm_t) and stream.  Stands where the
+ * reference relies on DDP's gradient all-reduce (rnnt/train.py:28,68: backend "nccl" = RCCL on
+ * ROCm).  The engine does not link RCCL: ncclAllReduce is resolved at call time from the RCCL the
+ * process already has loaded (PyTorch's), else from librccl.so.1 on the loader path; it creates no
+ * communicator and keeps none.  Returns RNNT_ERR_UNSUPPORTED when no RCCL can be found,
+ * RNNT_ERR_LAUNCH with RCCL's message when the collective fails.
+ */
+int rnnt_engine_allreduce(void *buf, size_t count, void *comm, void *stream);
+
+/*
  * Diagnostic view of the last fused call's intermediate buffers inside `workspace`
  * (offsets in bytes; valid for the dims given).  Used by tests and bench.py to time or
  * inspect single stages; not needed by training code.

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 
 #include "kernels.hpp"
@@ -345,6 +346,33 @@ void rnnt_engine_set_debug(void *) {}
 int rnnt_engine_debug_query(int what) { return fwd_occupancy(what); }
 
 const char *rnnt_engine_last_error(void) { return g_err.c_str(); }
+
+// ---- RCCL all-reduce of the flat gradient buffer.  No link-time dependency: the symbol
+// comes from the RCCL already in the process (soname librccl.so.1: PyTorch-ROCm's copy when torch is
+// loaded), so the communicator the caller made and the function called belong to the same library.
+int rnnt_engine_allreduce(void *buf, size_t count, void *comm, void *stream)
+{
+    if (!buf || !comm) return fail(RNNT_ERR_INVALID_ARG, "null buffer / communicator");
+    if (count == 0) return RNNT_OK;
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef const char *(*errstr_fn)(int);
+    void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    void *lib = nullptr;
+    if (!sym) {
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the copy that is already loaded
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW);
+        if (lib) sym = dlsym(lib, "ncclAllReduce");
+    }
+    if (!sym) return fail(RNNT_ERR_UNSUPPORTED, "RCCL (librccl.so.1: ncclAllReduce) not found in this process");
+    const int ncclFloat32_ = 7, ncclSum_ = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+    const int rc = ((allreduce_fn)sym)(buf, buf, count, ncclFloat32_, ncclSum_, comm, (hipStream_t)stream);
+    if (rc != 0) {
+        void *es = lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+        return fail(RNNT_ERR_LAUNCH, "ncclAllReduce failed (%d): %s", rc, es ? ((errstr_fn)es)(rc) : "?");
+    }
+    return RNNT_OK;
+}
 
 int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,
                                  rnnt_engine_ws_layout *out)

@@ -8,6 +8,9 @@ flat [dW | db | loss] buffer.  Under the reference's own DDP wrapper (rnnt/train
 joint parameters are ordinary nn.Parameters and DDP's bucketed all-reduce covers them; this
 module is for the standalone benchmark and for code that wants the global loss.
 """
+import ctypes
+import os
+
 import torch
 
 
@@ -35,8 +38,73 @@ class FlatGrad:
     def loss(self) -> torch.Tensor:
         return self.flat[self.V * self.H + self.V]
 
-    def all_reduce(self, group=None):
+    def all_reduce(self, group=None, comm=None):
+        """SUM over ranks (shards already carry 1/B_global): `comm` (an RcclComm) sends the buffer through
+        the engine's C entry rnnt_engine_allreduce, otherwise torch.distributed's backend does it."""
+        if comm is not None:
+            comm.all_reduce(self.flat)
+            return self
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, group=group)  # SUM; shards already carry 1/B_global
+            dist.all_reduce(self.flat, group=group)
         return self
+
+
+class _UniqueId(ctypes.Structure):  # rccl.h: ncclUniqueId, NCCL_UNIQUE_ID_BYTES = 128
+    _fields_ = [("internal", ctypes.c_ubyte * 128)]
+
+
+class RcclComm:
+    """An RCCL communicator of this process's own, one rank per GPU, for rnnt_engine_allreduce
+    (include/rnnt_engine.h): rank 0 draws the unique id (ncclGetUniqueId), `exchange(bytes) -> bytes`
+    hands it to the other ranks (default: torch.distributed.broadcast_object_list on the default
+    group, any backend — it only carries 128 bytes), ncclCommInitRank joins.  The RCCL used is the one
+    PyTorch-ROCm has loaded, the same copy the engine resolves.  Collectives run on the current stream.
+
+    Verified with one rank on an MI355X (tests/test_train_step.py); no multi-GPU box was available to
+    the build, so bench.py keeps torch.distributed ("nccl" = RCCL) as its default transport."""
+
+    def __init__(self, rank: int, world: int, device, exchange=None):
+        from . import engine
+        self._engine = engine
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._rccl = ctypes.CDLL(path if os.path.exists(path) else "librccl.so.1")
+        self._rccl.ncclGetErrorString.restype = ctypes.c_char_p
+        uid = _UniqueId()
+        if rank == 0:
+            self._ok(self._rccl.ncclGetUniqueId(ctypes.byref(uid)))
+        raw = bytes(uid) if rank == 0 else None  # all 128 bytes (not a C string)
+        if world > 1:
+            if exchange is None:
+                import torch.distributed as dist
+
+                def exchange(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            raw = exchange(raw)
+        ctypes.memmove(ctypes.byref(uid), raw, 128)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._ok(self._rccl.ncclCommInitRank(ctypes.byref(self._comm), ctypes.c_int(world), uid, ctypes.c_int(rank)))
+
+    def _ok(self, rc):
+        if rc != 0:
+            raise RuntimeError("RCCL: " + self._rccl.ncclGetErrorString(rc).decode())
+
+    def all_reduce(self, flat: torch.Tensor):
+        """In-place SUM of a contiguous fp32 device tensor over the ranks, on the current stream."""
+        e = self._engine
+        e._require_cuda(flat)
+        e._require_dtype(torch.float32, flat=flat)
+        e._require_contiguous(flat=flat)
+        with torch.cuda.device(flat.device):
+            e._check(e.lib().rnnt_engine_allreduce(e._p(flat), ctypes.c_size_t(flat.numel()), self._comm,
+                                                   e._stream(flat.device)))
+        return flat
+
+    def destroy(self):
+        if self._comm:
+            self._rccl.ncclCommDestroy(self._comm)
+            self._comm = ctypes.c_void_p()

@@ -112,3 +112,10 @@ def test_greedy_scan_entry_validation(lib):
     rc = lib.rnnt_engine_greedy_scan(None, ctypes.c_int64(512), ctypes.c_int64(1), None, None, None, 0, 8, 512,
                                      1024, 1023, None, None, ctypes.c_size_t(0), None)
     assert rc == -1 and b"null" in lib.rnnt_engine_last_error()
+
+
+def test_allreduce_entry_validation(lib):
+    """rnnt_engine_allreduce refuses null arguments before it looks for RCCL (no GPU, no RCCL call)."""
+    lib.rnnt_engine_last_error.restype = ctypes.c_char_p
+    assert lib.rnnt_engine_allreduce(None, ctypes.c_size_t(8), None, None) == -1
+    assert b"null" in lib.rnnt_engine_last_error()

@@ -151,7 +151,36 @@ def test_train_step_sequence_ddp_world1(hidden, proj, conv_pred):
         dist.destroy_process_group()
 
 
-def test_bench_nccl_path_with_one_rank():
+def test_engine_allreduce_on_an_rccl_communicator_of_one_rank():
+    """rnnt_engine_allreduce (include/rnnt_engine.h; SURVEY §8b's suggested export) on a real RCCL
+    communicator — one rank, all this box has: ncclGetUniqueId / ncclCommInitRank through
+    rnnt_amd.parallel.RcclComm, the sum of one rank's buffer is the buffer."""
+    import rnnt_amd
+    from rnnt_amd.parallel import FlatGrad, RcclComm
+
+    assert torch.cuda.is_available()
+    rnnt_amd.engine.lib()
+    dev = torch.device("cuda:0")
+    comm = RcclComm(0, 1, dev)
+    try:
+        fg = FlatGrad(64, 32, dev)
+        fg.flat.copy_(torch.arange(fg.flat.numel(), dtype=torch.float32))
+        want = fg.flat.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # the caller's stream is honoured
+            fg.all_reduce(comm=comm)
+            fg.all_reduce(comm=comm)
+        s.synchronize()
+        assert torch.equal(fg.flat, want)
+        with pytest.raises(RuntimeError):
+            comm.all_reduce(torch.zeros(4, dtype=torch.float64, device=dev))
+    finally:
+        comm.destroy()
+
+
+@pytest.mark.parametrize("via", ["torch", "engine"])
+def test_bench_nccl_path_with_one_rank(via):
     """bench.py's N>1 code path (process group "nccl" = RCCL, broadcast, all-reduce of the flat
     [dW | db | loss] buffer, barriers) with a single rank on this one-GPU box."""
     import json
@@ -159,6 +188,8 @@ def test_bench_nccl_path_with_one_rank():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    if via == "engine":
+        env["BENCH_COMM"] = "engine"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "small", "--steps", "2",
@@ -168,6 +199,7 @@ def test_bench_nccl_path_with_one_rank():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["hipGetDeviceCount"] >= 1
     assert line["value"] > 0 and np.isfinite(line["loss"])
+    assert line["allreduce_via"] == ("rnnt_engine_allreduce" if via == "engine" else "torch.distributed")
 
 
 def test_forward_backward_as_one_hip_graph():
