@@ -879,10 +879,14 @@ void launch_dw_bf16(const Bf16Args &a, hipStream_t st)
 {
     launch_dw_table(a.logit_lens, a.B, a.T, a.U1, BW_ROWS, a.dw_tab, st);
     const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per process
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs the opt-in, once per DEVICE (a function attribute belongs to the
+    // device's code object); a read-mostly fact, like device_cus()
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;  // unknown: set it every time
+    if (dev < 0 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)k_dw_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, BW_NST * 32768);
-        attr_set = true;
+        if (dev >= 0) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(k_dw_bf16, dim3(tiles * a.n_split), dim3(256), BW_NST * 32768, st, a);
 }

@@ -70,3 +70,18 @@ o2 = o[len(o)//2:len(o)//2+16]
 print("   ... mid-kernel:")
 for i in o2:
     print(f"   {int(st[i]-t00)//1000:7d} {int(en[i]-t00)//1000:7d}  slot {int(slot[i])}")
+# ---- the same CU, mid-kernel: every stamp of consecutive workgroups (k-cycles since the CU's first start),
+# wave 0's view: s0 start | s1 main0 begins | s2 main0 ends | s3 main1 begins | s4 main1 ends | s5 epilogue1 done | s6 end
+dm = d[m]
+print("   slot     s0      s1      s2      s3      s4      s5      s6   | pro  main0  epi0  main1  epi1  final")
+for i in o2:
+    s = (dm[i, 0:7] - t00) / 1000.0
+    ph = np.diff(s)
+    print(f"   {int(slot[i])}   " + " ".join(f"{x:7.0f}" for x in s) + "   | " + " ".join(f"{x:5.0f}" for x in ph))
+# per-slot medians of the phases over all workgroups
+for sl in (0, 1):
+    ms = wv == sl
+    print(f"slot {sl}: " + "  ".join(f"{n} {np.median(d[ms, i + 1] - d[ms, i]):8.0f}" for i, n in enumerate(names)))
+# per-wave end of the last pass relative to wave 0 (are the four waves of a workgroup in step?)
+wend4 = d[:, 16:20] - d[:, 16:17]
+print("end of passes, waves 1..3 minus wave 0: median", np.median(wend4, axis=0).astype(int), " p10", np.percentile(wend4, 10, axis=0).astype(int), " p90", np.percentile(wend4, 90, axis=0).astype(int))
