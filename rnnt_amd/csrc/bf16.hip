@@ -47,6 +47,18 @@ __device__ __forceinline__ unsigned pack_f16(float lo, float hi)
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));  // v_cvt_pk_f16_f32 (RNE)
 }
+__device__ __forceinline__ unsigned pk_max_f16(unsigned x, unsigned y)  // max of two pairs of halves
+{
+    unsigned d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ unsigned max_halves_f16(unsigned x)  // low half of the result = max(lo, hi) of x
+{
+    unsigned d;
+    asm("v_max_f16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(d) : "v"(x));
+    return d;
+}
 __device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
 __device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
@@ -251,11 +263,18 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
     const u32x4 *ap = (const u32x4 *)(a.hidden + (row0 + j) * H) + 2 * half;  // chunk c: ap[4c], ap[4c+1]
     const u32x4 *wp = (const u32x4 *)a.wpack_fwd;
 
+    // the accumulators start from the bias of the pass's columns (this lane's 8 adjacent ones): the pass
+    // epilogue then has no bias add — VALU instructions share the issue port with the MFMA stream of the
+    // CU's other workgroup, every one of them counts
     f32x16 acc[NT];
+    {
+        const int c0 = 8 * j;  // pass 0
+        const f32x4 b0 = *(const f32x4 *)(a.bias + c0), b1 = *(const f32x4 *)(a.bias + c0 + 4);
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl)
+        for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[tl][r] = tl < 4 ? b0[tl] : b1[tl - 4];
+    }
 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s_stat[0][r][tid] = RNNT_NEG_INF; s_stat[1][r][tid] = 0.f; }
@@ -289,25 +308,31 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
             if (q == 3 && c + 4 == KC) {  // pass complete (KC % 4 == 0): bias, store, softmax statistics
                 const int col0 = 256 * pass + 8 * j;  // this lane's 8 adjacent columns
                 const bool cok = col0 < V;            // V % 128 == 0: the last pass may be half empty
-                const f32x4 b0 = *(const f32x4 *)(a.bias + (cok ? col0 : 0));
-                const f32x4 b1 = *(const f32x4 *)(a.bias + (cok ? col0 + 4 : 0));
+                // bias of the NEXT pass's columns, requested before the row loop, used after it
+                const int coln = col0 + 256 < V ? col0 + 256 : 0;
+                const f32x4 b0 = *(const f32x4 *)(a.bias + coln);
+                const f32x4 b1 = *(const f32x4 *)(a.bias + coln + 4);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     // fp16 logits: round, store, and take the statistics from the rounded values
-                    const u32x4 qv = {pack_f16(acc[0][r] + b0[0], acc[1][r] + b0[1]), pack_f16(acc[2][r] + b0[2], acc[3][r] + b0[3]),
-                                      pack_f16(acc[4][r] + b1[0], acc[5][r] + b1[1]), pack_f16(acc[6][r] + b1[2], acc[7][r] + b1[3])};
+                    const u32x4 qv = {pack_f16(acc[0][r], acc[1][r]), pack_f16(acc[2][r], acc[3][r]),
+                                      pack_f16(acc[4][r], acc[5][r]), pack_f16(acc[6][r], acc[7][r])};
                     // streaming stores: the logits are not re-read by this kernel's CUs and should
                     // not evict the A rows the next pass re-reads from L2
                     if (cok && !RNNT_XP(a.flags, 256)) __builtin_nontemporal_store(qv, (u32x4 *)(a.logits + orow * V + col0));
                     const f32x4 o0 = {f16_lo(qv[0]), f16_hi(qv[0]), f16_lo(qv[1]), f16_hi(qv[1])};
                     const f32x4 o1 = {f16_lo(qv[2]), f16_hi(qv[2]), f16_lo(qv[3]), f16_hi(qv[3])};
                     if (RNNT_XP(a.flags, 512) || !cok) continue;  // columns past V (zero weights) are no logits
-                    // running (max, sum exp) of this lane's columns of row-slot r
-                    const float lmax = fmaxf(fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3])),
-                                             fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                    // running (max, sum exp) of this lane's columns of row-slot r.  The max of the 8 rounded
+                    // values is taken on the packed halves (3 v_pk_max_f16 + 1 + one conversion instead of 8
+                    // conversions + 7 max; the exp arguments below read the halves through v_fma_mix_f32)
+                    // (spelled as asm: __builtin_elementwise_max on the half pairs was reduced by hipcc 7.2 to
+                    // the max of the first pair only)
+                    const float lmax = f16_lo(max_halves_f16(pk_max_f16(pk_max_f16(qv[0], qv[1]), pk_max_f16(qv[2], qv[3]))));
                     const float m_old = s_stat[0][r][tid];
-                    const float mn = fmaxf(m_old, lmax);
+                    float mn;  // fmaxf would first canonicalise the LDS value (one more instruction); -inf / finite only
+                    asm("v_max_f32 %0, %1, %2" : "=v"(mn) : "v"(m_old), "v"(lmax));
                     const float nm2 = -mn * RNNT_LOG2E;
                     float e = s_stat[1][r][tid] * __builtin_amdgcn_exp2f(fmaf(m_old, RNNT_LOG2E, nm2));
                     e += (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) +
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
 #pragma unroll
                 for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[tl][r] = tl < 4 ? b0[tl] : b1[tl - 4];
             }
             lds_barrier();
         }
@@ -336,10 +361,11 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
     // Row-slot r of half h is row (r&3) + 8*(r>>2) + 4h of the wave's 32; its 32 lanes combine.
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+        // on the DPP crossbar (as the fp32 forward): the ds_bpermute butterflies were 160 LDS round trips
         const float m_l = s_stat[0][r][tid];
-        const float M = half_max(m_l);
-        const float S = half_sum(s_stat[1][r][tid] * __builtin_amdgcn_exp2f((m_l - M) * RNNT_LOG2E));
-        if (j == 0) s_den[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = M + __logf(S);
+        const float M = half_max_dpp(m_l, half);
+        const float S = half_sum_dpp(s_stat[1][r][tid] * __builtin_amdgcn_exp2f((m_l - M) * RNNT_LOG2E), half);
+        if (j == 31) s_den[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = M + __logf(S);  // lanes 31 / 63 hold the sums
     }
     // lane L: row L&31; lanes 0-31 fetch logit[blank], lanes 32-63 logit[label].  Both were
     // stored by THIS wave: wait for the stores, then read through L2 (agent-scope loads bypass
