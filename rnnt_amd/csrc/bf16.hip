@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
     // CU's other workgroup, every one of them counts
     f32x16 acc[NT];
     {
-        const int c0 = 8 * j;  // pass 0
+        const int c0 = 8 * j < V ? 8 * j : 0;  // pass 0 (V = 128: the upper half of the pass has no columns)
         const f32x4 b0 = *(const f32x4 *)(a.bias + c0), b1 = *(const f32x4 *)(a.bias + c0 + 4);
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl)
