@@ -838,3 +838,44 @@ def test_two_streams_do_not_share_scratch(amd):
     for got, want in ((res["a"], want_a), (res["b"], want_b)):
         for x, y in zip(got, want):
             assert torch.equal(x, y)
+
+
+def _guarded(shape, dtype, margin=4096, fill=-7.25):
+    """A tensor of `shape` inside a larger buffer whose margins carry a sentinel value: an out-of-bounds
+    WRITE of a kernel shows up as a changed margin."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    buf = torch.full((n + 2 * margin,), fill, dtype=dtype, device="cuda")
+    return buf, buf[margin:margin + n].view(shape)
+
+
+@pytest.mark.parametrize("dtype,shape", [("fp32", (3, 37, 11, 128, 132)), ("fp32", (2, 50, 21, 1024, 64)), ("fp32", (2, 33, 9, 640, 260)),
+                                         ("bf16", (3, 37, 11, 128, 128)), ("bf16", (2, 26, 17, 1024, 256))])
+def test_kernels_write_only_inside_outputs_and_workspace(amd, dtype, shape, monkeypatch):
+    """Every output and the workspace sit inside larger buffers with sentinel margins (the workspace at the
+    exact size rnnt_engine_workspace_bytes asks for): after a fused call on a ragged batch the margins are
+    untouched and the result is the one computed in ordinary allocations."""
+    B, T, U, H, V = shape
+    d = make_inputs(B, T, U, H, V, seed=4000 + H + V)
+    g = _dev(d)
+    want = [o.clone() for o in _fused_outs(amd, g, dtype=dtype)]
+    torch.cuda.synchronize()
+    bufs, outs = zip(*[_guarded(tuple(o.shape), torch.float32) for o in want])
+    ws_holder = {}
+
+    def guarded_workspace(device, nbytes):
+        # 256-byte aligned start inside a byte buffer with 64 KiB sentinel margins
+        buf = torch.full((int(nbytes) + 2 * 65536,), 0x5A, dtype=torch.uint8, device=device)
+        off = 65536 + (-(buf.data_ptr() + 65536)) % 256
+        ws_holder["buf"], ws_holder["off"], ws_holder["n"] = buf, off, int(nbytes)
+        return buf[off:off + int(nbytes)]
+
+    monkeypatch.setattr(amd.engine, "workspace", guarded_workspace)
+    got = _fused_outs(amd, g, outs=outs, dtype=dtype)
+    torch.cuda.synchronize()
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+    for buf, o in zip(bufs, outs):
+        n = o.numel()
+        assert (buf[:4096] == -7.25).all() and (buf[4096 + n:] == -7.25).all()
+    buf, off, n = ws_holder["buf"], ws_holder["off"], ws_holder["n"]
+    assert (buf[:off] == 0x5A).all() and (buf[off + n:] == 0x5A).all()
