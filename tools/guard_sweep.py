@@ -52,3 +52,50 @@ for dtype, (B, T, U, H, V) in CASES:
     assert_close_loss("costs", outs[0].cpu().numpy(), ref["costs"], rtol=BF16_LOSS_RTOL if dtype == "bf16" else 1e-4)
     print("   ok", flush=True)
 print("guard sweep clean:", len(CASES), "cases")
+
+# ---- the other entry points: unfused joint forward / backward, standalone loss, projections, ConvPredictor,
+# greedy-decode scan — inputs again end at unmapped pages
+rng = np.random.default_rng(5)
+G = lambda a: guarded(np.ascontiguousarray(a))[0]
+for (B, T, U, H, V) in [(2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 13, 6, 640, 1024), (2, 40, 33, 72, 520), (1, 64, 40, 32, 1300)]:
+    d = make_inputs(B, T, U, H, V, seed=1 + H + V)
+    enc, pred, W, bias = G(d["enc"]), G(d["pred"]), G(d["W"]), G(d["bias"])
+    logits = amd.engine.joint_fwd(enc, pred, W, bias)
+    gl = G(rng.standard_normal((B, T, U + 1, V)).astype(np.float32))
+    amd.engine.joint_bwd(enc, pred, W, gl)
+    lg = G(logits.cpu().numpy())
+    amd.engine.loss_fwd_bwd(lg, G(d["targets"]), G(d["logit_lens"]), G(d["target_lens"]), V - 1)
+    amd.engine.joint_loss_fwd(enc, pred, W, bias, G(d["targets"]), G(d["logit_lens"]), G(d["target_lens"]), V - 1)
+    torch.cuda.synchronize()
+    print(f"unfused entries ok B={B} T={T} U={U} H={H} V={V}", flush=True)
+for (M, K, N) in [(7, 12, 8), (250, 96, 256), (1000, 1024, 1024), (33, 516, 260), (3000, 256, 1024)]:
+    x, Wl, bl = G(rng.standard_normal((M, K)).astype(np.float32)), G(rng.standard_normal((N, K)).astype(np.float32)), G(rng.standard_normal(N).astype(np.float32))
+    y = amd.engine.linear_fwd(x, Wl, bl)
+    amd.engine.linear_bwd(x, Wl, G(rng.standard_normal((M, N)).astype(np.float32)))
+    torch.cuda.synchronize()
+    print(f"linear ok M={M} K={K} N={N}", flush=True)
+for (S, O, E, B, U1) in [(17, 24, 12, 2, 5), (64, 96, 128, 3, 31), (1024, 1024, 512, 4, 101), (33, 260, 36, 1, 1)]:
+    m = amd.ConvPredictor(S, O, E, dropout=0.25).cuda().train()
+    with torch.no_grad():
+        for p in m.parameters():  # parameters themselves against unmapped pages
+            p.data = G(p.detach().cpu().numpy())
+    ids = G(rng.integers(0, S, (B, U1)).astype(np.int64))
+    out = m(ids)
+    out.backward(G(rng.standard_normal(tuple(out.shape)).astype(np.float32)))
+    torch.cuda.synchronize()
+    print(f"ConvPredictor ok S={S} O={O} E={E} B={B} U1={U1}", flush=True)
+for (T, H, V, n) in [(50, 512, 1024, 32), (7, 64, 128, 7), (130, 1024, 1024, 128)]:
+    enc1, pr1 = G(rng.standard_normal((T, H)).astype(np.float32)), G(rng.standard_normal(H).astype(np.float32))
+    W1, b1 = G((rng.standard_normal((V, H)) / np.sqrt(H)).astype(np.float32)), G(rng.standard_normal(V).astype(np.float32))
+    for t0 in (0, max(0, T - n)):
+        amd.engine.greedy_scan(enc1, pr1, W1, b1, t0, min(n, T - t0), V - 1)
+    torch.cuda.synchronize()
+    print(f"greedy_scan ok T={T} H={H} V={V}", flush=True)
+ps = [G(rng.standard_normal(s).astype(np.float32)).requires_grad_(True) for s in [(1024, 512), (3,), (16385,), (7, 9, 5), (1,)]]
+for p in ps:
+    p.grad = G(rng.standard_normal(tuple(p.shape)).astype(np.float32))
+opt = amd.optim.AdamW(ps, lr=1e-3, max_grad_norm=1.0)
+opt.step(); amd.optim.clip_grad_norm_(ps, 0.5)
+torch.cuda.synchronize()
+print("optim ok")
+print("guard sweep of the other entry points clean")
