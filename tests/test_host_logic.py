@@ -149,3 +149,26 @@ def test_projected_joint_single_forward_stays_plain_torch_on_cpu(golden_dir):
     a, t = torch.from_numpy(z["audio"]), torch.from_numpy(z["text"])
     out = m.single_forward(a[:, 1, :], t[:, 2, :]).detach().numpy()
     np.testing.assert_allclose(out, z["logits_f32"][:, 1, 2, :], rtol=0, atol=2e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/rnnt"), reason="needs the reference checkout (build container only)")
+def test_overlay_package_swaps_joint_and_model_only():
+    """integration/rnnt placed before the reference on PYTHONPATH: `rnnt.joint.JointNetwork` (the hydra
+    target, train.py:63) and `rnnt.model.RNNTModel` (train.py:19) become the engine's classes — rnnt.model
+    imports without torchaudio — while rnnt.predictor / rnnt.jasper / rnnt.lr_sched still come from the
+    reference's own files."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import rnnt, rnnt.joint, rnnt.model, rnnt.predictor, rnnt.jasper, rnnt.lr_sched, rnnt_amd\n"
+        "assert rnnt.joint.JointNetwork is rnnt_amd.JointNetwork\n"
+        "assert rnnt.model.RNNTModel is rnnt_amd.RNNTModel\n"
+        "assert rnnt.predictor.__file__.startswith('/root/reference/'), rnnt.predictor.__file__\n"
+        "assert rnnt.jasper.__file__.startswith('/root/reference/')\n"
+        "m = rnnt.model.RNNTModel(rnnt.predictor.ConvPredictor(16, 32, 8, 0.1), rnnt.jasper.AudioEncoder if False else None, rnnt.joint.JointNetwork(-1, -1, 32, 16))\n"
+        "assert sorted(k for k in m.state_dict() if k.startswith('joint.')) == ['joint.joint_ln.bias', 'joint.joint_ln.weight']\n"
+        "print('overlay ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "integration"), root, "/root/reference"]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "overlay ok" in out.stdout, out.stderr[-1500:]
