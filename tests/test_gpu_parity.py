@@ -61,6 +61,10 @@ FUSED_SHAPES = [
     # dPred slab heights in one reduction)
     (3, 21, 18, 1024, 64), (2, 10, 35, 768, 160), (2, 13, 6, 640, 1024), (2, 9, 4, 516, 96),
     (2, 19, 7, 1536, 32), (2, 11, 20, 1152, 96), (3, 33, 5, 1028, 64),
+    # BASELINE config 2's / config 4's lattice lengths through the whole fused pipeline at a joint small
+    # enough for the oracle: 1 200 / 2 100 dependent sweep steps (chained waves / the barrier kernel of
+    # lattices wider than the mailbox), alpha and beta around 1e3-1e4
+    (2, 1000, 200, 32, 64), (1, 1500, 600, 16, 32),
 ]
 
 
