@@ -625,7 +625,9 @@ def test_fused_vs_unfused_reference_joint_width(amd):
 BF16_SHAPES = [(1, 1, 0, 128, 128), (2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024),
                (4, 30, 12, 384, 256), (1, 70, 40, 128, 2048),
                # H > 512: one more k_dhidden_bf16 launch per further 512 columns (G read back in place)
-               (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128)]
+               (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128),
+               # config 3's lattice length (T = 1000, U = 200: 1 200 sweep steps on fp16-rounded logits)
+               (1, 1000, 200, 128, 128)]
 
 
 @pytest.mark.parametrize("shape", BF16_SHAPES)
