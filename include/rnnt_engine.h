@@ -198,6 +198,12 @@ int rnnt_engine_greedy_scan(const void *enc, int64_t enc_stride_t, int64_t enc_s
  *                           coefficient, read on the device: no host synchronisation between
  *                           backward and step; write_clipped_grads != 0 also stores the scaled
  *                           gradients (clip_grad_norm_ works in place).
+ *   rnnt_engine_adamw_step_dev  the same update with the step count and the learning rate RESIDENT ON THE
+ *                           DEVICE: `step_dev` (int64, the count of updates done so far) is incremented
+ *                           by the call, `lr_dev` (float) is read when the kernels run, the three derived
+ *                           scalars go through `hyper_dev` (float[4], scratch).  Nothing of the update is
+ *                           baked into the launch arguments, so the call can be captured into a HIP graph
+ *                           and replayed every iteration (an LR scheduler writes lr_dev between replays).
  */
 int rnnt_engine_grad_norm_workspace_bytes(int n_tensors, const int64_t *numels, size_t *out);
 int rnnt_engine_grad_norm(int n_tensors, const void *const *grads, const int64_t *numels,
@@ -207,6 +213,12 @@ int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const
                            double lr, double beta1, double beta2, double eps, double weight_decay,
                            int64_t step, const float *total_norm, float max_norm,
                            int write_clipped_grads, void *stream);
+int rnnt_engine_adamw_step_dev(int n_tensors, void *const *params, const void *const *grads,
+                               void *const *exp_avg, void *const *exp_avg_sq, const int64_t *numels,
+                               const float *lr_dev, double beta1, double beta2, double eps,
+                               double weight_decay, int64_t *step_dev, float *hyper_dev,
+                               const float *total_norm, float max_norm, int write_clipped_grads,
+                               void *stream);
 
 /*
  * ConvPredictor forward / backward (next-step row SURVEY.md 8f-3): reference rnnt/predictor.py:189-229

@@ -46,6 +46,9 @@ struct MtAdamArgs {
     float omb1, omb2, decay, step_size, bc2_sqrt;
     const float *total_norm;  // device scalar or NULL
     int write_grads;          // store the clipped gradients back (clip_grad_norm_ is in place)
+    // capturable form (rnnt_engine_adamw_step_dev): {decay, step_size, bc2_sqrt} prepared on the device by
+    // k_adam_prepare from a device step counter and a device learning rate; NULL: the by-value fields above
+    const float *dev_hyper;
 };
 
 template <class A>
@@ -106,8 +109,26 @@ __device__ __forceinline__ void adamw_one(float &p, float &g, float &m, float &v
     p -= a.step_size * (m / denom);         // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// step counter += 1, then the three scalars of this update in double, as the host path computes them
+__global__ void k_adam_prepare(long long *__restrict__ step, const float *__restrict__ lr, double beta1, double beta2,
+                               double weight_decay, float *__restrict__ hyper)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long t = step[0] + 1;
+    step[0] = t;
+    const double l = (double)lr[0];
+    hyper[0] = (float)(1.0 - l * weight_decay);
+    hyper[1] = (float)(l / (1.0 - pow(beta1, (double)t)));
+    hyper[2] = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
+
 __global__ __launch_bounds__(MT_THREADS) void k_mt_adamw(MtAdamArgs a)
 {
+    if (a.dev_hyper) {  // workgroup-uniform
+        a.decay = a.dev_hyper[0];
+        a.step_size = a.dev_hyper[1];
+        a.bc2_sqrt = a.dev_hyper[2];
+    }
     const int t = mt_find(a, blockIdx.x);
     const long base = (long)(blockIdx.x - a.chunk0[t]) * MT_CHUNK;
     float *p = a.p[t] + base, *m = a.m[t] + base, *v = a.v[t] + base;
@@ -198,6 +219,11 @@ int rnnt_engine_grad_norm(int n_tensors, const void *const *grads, const int64_t
     return RNNT_OK;
 }
 
+namespace {
+int adamw_launch(MtAdamArgs &a, int n_tensors, void *const *params, const void *const *grads, void *const *exp_avg,
+                 void *const *exp_avg_sq, const int64_t *numels, hipStream_t st);
+}
+
 int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const *grads,
                            void *const *exp_avg, void *const *exp_avg_sq, const int64_t *numels,
                            double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -209,7 +235,6 @@ int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const
     if (step < 1) return engine_fail(RNNT_ERR_INVALID_ARG, "step must be >= 1 (the count AFTER this update)");
     if (!(lr >= 0.) || !(eps >= 0.) || !(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(weight_decay >= 0.))
         return engine_fail(RNNT_ERR_INVALID_ARG, "invalid AdamW hyper-parameter");
-    hipStream_t st = (hipStream_t)stream;
     MtAdamArgs a;
     // scalar arithmetic in double on the host, as torch does with python floats (1 - 0.9999 in
     // fp32 would be off by 1.6e-4 relative)
@@ -219,6 +244,38 @@ int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const
     a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
     a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
     a.max_norm = max_norm; a.total_norm = total_norm; a.write_grads = write_clipped_grads;
+    a.dev_hyper = nullptr;
+    return adamw_launch(a, n_tensors, params, grads, exp_avg, exp_avg_sq, numels, (hipStream_t)stream);
+}
+
+int rnnt_engine_adamw_step_dev(int n_tensors, void *const *params, const void *const *grads,
+                               void *const *exp_avg, void *const *exp_avg_sq, const int64_t *numels,
+                               const float *lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                               int64_t *step_dev, float *hyper_dev, const float *total_norm, float max_norm,
+                               int write_clipped_grads, void *stream)
+{
+    if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numels)))
+        return engine_fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    if (!lr_dev || !step_dev || !hyper_dev) return engine_fail(RNNT_ERR_INVALID_ARG, "null device scalar (lr / step / hyper)");
+    if (!(eps >= 0.) || !(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(weight_decay >= 0.))
+        return engine_fail(RNNT_ERR_INVALID_ARG, "invalid AdamW hyper-parameter");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, st, (long long *)step_dev, lr_dev, beta1, beta2, weight_decay, hyper_dev);
+    MtAdamArgs a;
+    a.beta2 = (float)beta2; a.eps = (float)eps;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+    a.decay = 1.f; a.step_size = 0.f; a.bc2_sqrt = 1.f;  // replaced on the device
+    a.max_norm = max_norm; a.total_norm = total_norm; a.write_grads = write_clipped_grads;
+    a.dev_hyper = hyper_dev;
+    return adamw_launch(a, n_tensors, params, grads, exp_avg, exp_avg_sq, numels, st);
+}
+
+}  // extern "C"
+
+namespace {
+int adamw_launch(MtAdamArgs &a, int n_tensors, void *const *params, const void *const *grads, void *const *exp_avg,
+                 void *const *exp_avg_sq, const int64_t *numels, hipStream_t st)
+{
     for (int i0 = 0; i0 < n_tensors;) {
         a.count = 0;
         a.chunk0[0] = 0;
@@ -243,5 +300,4 @@ int rnnt_engine_adamw_step(int n_tensors, void *const *params, const void *const
     if (e != hipSuccess) return engine_fail(RNNT_ERR_LAUNCH, "%s", hipGetErrorString(e));
     return RNNT_OK;
 }
-
-}  // extern "C"
+}  // namespace

@@ -41,6 +41,7 @@ EXPORTS = (
     "rnnt_engine_joint_loss_fwd", "rnnt_engine_run_stages",
     "rnnt_engine_joint_bwd_workspace_bytes", "rnnt_engine_joint_bwd",
     "rnnt_engine_grad_norm_workspace_bytes", "rnnt_engine_grad_norm", "rnnt_engine_adamw_step",
+    "rnnt_engine_adamw_step_dev",
     "rnnt_engine_conv_predictor_saved_bytes", "rnnt_engine_conv_predictor_fwd",
     "rnnt_engine_conv_predictor_bwd", "rnnt_engine_linear_fwd", "rnnt_engine_linear_bwd_workspace_bytes",
     "rnnt_engine_linear_bwd", "rnnt_engine_allreduce",

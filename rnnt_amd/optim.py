@@ -87,12 +87,18 @@ class AdamW(torch.optim.Optimizer):
     host.  `last_grad_norm` then holds the device scalar."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 max_grad_norm=None):
-        if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
+                 max_grad_norm=None, capturable=False):
+        if float(lr) < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("rnnt_amd.optim.AdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.last_grad_norm = None
+        # capturable=True (as torch.optim.AdamW's flag): the step count and the learning rate live on the
+        # device (rnnt_engine_adamw_step_dev) — nothing of an update is baked into the launches, so step()
+        # can be captured into a HIP graph together with forward and backward.  group["lr"] becomes a
+        # device tensor that LR schedulers fill in place; every parameter must have a gradient each step.
+        self.capturable = bool(capturable)
+        self._dev = {}  # group index -> (step int64[1], hyper float32[4])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -107,7 +113,7 @@ class AdamW(torch.optim.Optimizer):
             if allg:
                 total = grad_norm(allg)
                 self.last_grad_norm = total
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
@@ -116,6 +122,9 @@ class AdamW(torch.optim.Optimizer):
                 raise RuntimeError("rnnt_amd.optim.AdamW does not support sparse gradients")
             dev = _check_group(ps, "parameters")
             _check_group(gs, "gradients")
+            if self.capturable:
+                self._step_capturable(lib, gi, group, ps, gs, dev, total)
+                continue
             ms, vs = [], []
             for p in ps:
                 st = self.state[p]
@@ -145,3 +154,39 @@ class AdamW(torch.optim.Optimizer):
                         ctypes.c_float(self.max_grad_norm if total is not None else -1.0), 1,
                         engine._stream(dev)))
         return loss
+
+    def _step_capturable(self, lib, gi, group, ps, gs, dev, total):
+        if len(ps) != len(group["params"]):
+            raise RuntimeError("rnnt_amd.optim.AdamW(capturable=True): every parameter of a group needs a gradient "
+                               "each step (one device step counter per group)")
+        if gi not in self._dev:
+            step0 = 0
+            for p in ps:  # a loaded checkpoint carries the count (int, or tensor from torch's own AdamW)
+                st = self.state[p]
+                if "step" in st:
+                    step0 = max(step0, int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"]))
+            self._dev[gi] = (torch.full((1,), step0, dtype=torch.int64, device=dev),
+                             torch.zeros(4, dtype=torch.float32, device=dev))
+        step_dev, hyper = self._dev[gi]
+        lr = group["lr"]
+        if not torch.is_tensor(lr):
+            lr = group["lr"] = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        if lr.device != dev or lr.dtype != torch.float32:
+            raise RuntimeError("rnnt_amd.optim.AdamW(capturable=True): lr must be a float32 tensor on the parameters' device")
+        ms, vs = [], []
+        for p in ps:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["step"] = step_dev  # shared device counter (state_dict() stores its value per parameter)
+            ms.append(st["exp_avg"])
+            vs.append(st["exp_avg_sq"])
+        b1, b2 = group["betas"]
+        with torch.cuda.device(dev):
+            engine._check(lib.rnnt_engine_adamw_step_dev(
+                len(ps), _ptr_array(ps), _ptr_array(gs), _ptr_array(ms), _ptr_array(vs), _numel_array(ps),
+                engine._p(lr), ctypes.c_double(b1), ctypes.c_double(b2), ctypes.c_double(group["eps"]),
+                ctypes.c_double(group["weight_decay"]), engine._p(step_dev), engine._p(hyper),
+                engine._p(total) if total is not None else ctypes.c_void_p(0),
+                ctypes.c_float(self.max_grad_norm if total is not None else -1.0), 1, engine._stream(dev)))

@@ -131,3 +131,29 @@ def test_optimizer_checkpoint_moves_between_torch_and_engine(tmp_path):
         ref.step(); opt.step(); back.step()
     for x, y, z in zip(a, b, c):
         assert torch.allclose(x, y, rtol=3e-6, atol=1e-7) and torch.allclose(x, z, rtol=3e-6, atol=1e-7)
+
+
+def test_capturable_adamw_matches_torch_with_a_scheduler():
+    """capturable=True: step count and learning rate on the device (rnnt_engine_adamw_step_dev); an LR
+    scheduler fills the lr tensor in place (reference train.py:164-166: optimizer.step(); lr_scheduler.step())."""
+    import rnnt_amd
+    a, b = _params(9), _params(9)
+    ref = torch.optim.AdamW(a, foreach=False, fused=False, **HP)
+    opt = rnnt_amd.optim.AdamW(b, capturable=True, max_grad_norm=1.5, **HP)
+    lam = lambda s: min(1.0, (s + 1) / 4) * (0.9 ** s)
+    sched_ref = torch.optim.lr_scheduler.LambdaLR(ref, lam)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    for step in range(10):
+        _set_grads(a, 300 + step, scale=2.0)
+        _set_grads(b, 300 + step, scale=2.0)
+        torch.nn.utils.clip_grad_norm_(a, 1.5)
+        ref.step(); sched_ref.step()
+        opt.step(); sched.step()
+    assert torch.is_tensor(opt.param_groups[0]["lr"]) and opt.param_groups[0]["lr"].is_cuda
+    assert abs(float(opt.param_groups[0]["lr"]) - ref.param_groups[0]["lr"]) <= 1e-9
+    assert int(opt.state[b[0]]["step"]) == 10
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=3e-6, atol=1e-7)
+    b[3].grad = None
+    with pytest.raises(RuntimeError, match="every parameter"):
+        opt.step()

@@ -264,3 +264,75 @@ def test_forward_backward_as_one_hip_graph():
         # the captured gradient buffers stay the graph's outputs for the next replay
         for p, g in zip(params, static_grads):
             p.grad = g
+
+
+def test_whole_training_step_as_one_hip_graph():
+    """Forward + backward + fused clip + AdamW (capturable: step count and learning rate on the device)
+    of rnnt_amd.RNNTModel captured as ONE HIP graph and replayed over a sequence of batches, with an LR
+    scheduler stepping between replays, against the same sequence run eagerly on a twin model."""
+    import copy
+
+    import rnnt_amd
+
+    assert torch.cuda.is_available()
+    rnnt_amd.engine.lib()
+    device = torch.device("cuda:0")
+    torch.manual_seed(11)
+    vocab, n_mels, feats, hidden = 64, 16, 96, 256
+    model = rnnt_amd.RNNTModel(rnnt_amd.ConvPredictor(vocab, feats, 128, dropout=0.0), _Encoder(n_mels, feats),
+                               rnnt_amd.JointNetwork(feats, feats, hidden, vocab)).to(device).train()
+    twin = copy.deepcopy(model)
+    model.check_lengths = False
+    blank_idx = vocab - 1
+    hp = dict(lr=2e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, max_grad_norm=5.0)
+    lam = lambda s: min(1.0, (s + 1) / 3)
+    opt = rnnt_amd.optim.AdamW(model.parameters(), capturable=True, **hp)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lam)
+    opt_t = rnnt_amd.optim.AdamW(twin.parameters(), **hp)
+    sched_t = torch.optim.lr_scheduler.LambdaLR(opt_t, lam)
+    batches = [_batch(4, n_mels, 60, 10, vocab, seed=40 + i) for i in range(6)]
+    static = {k: v.to(device) for k, v in batches[0].items()}
+
+    def train_step(m, o, data):
+        o.zero_grad(set_to_none=False)
+        loss = m(data["mel_features"], data["mel_feature_lens"], data["input_ids"], data["input_id_lens"], blank_idx)
+        loss.backward()
+        o.step()
+        return loss
+
+    # eager twin over batches 0..5; the captured model: batches 0,1 eagerly on the side stream (warm-up:
+    # optimizer state, workspaces), then ONE captured step replayed for batches 2..5
+    want = []
+    for bt in batches:
+        want.append(train_step(twin, opt_t, {k: v.to(device) for k, v in bt.items()}).item())
+        sched_t.step()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    got = []
+    with torch.cuda.stream(s):
+        for i in range(2):
+            for k, v in batches[i].items():
+                static[k].copy_(v)
+            got.append(train_step(model, opt, static).item())
+            sched.step()
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        for k, v in batches[2].items():
+            static[k].copy_(v)
+        s.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            static_loss = train_step(model, opt, static)
+        s.synchronize()  # capture enqueued nothing: parameters and optimizer state are where batch 1 left them
+    torch.cuda.current_stream().wait_stream(s)
+    for i in range(2, 6):
+        for k, v in batches[i].items():
+            static[k].copy_(v)
+        graph.replay()
+        torch.cuda.synchronize()
+        got.append(static_loss.item())
+        sched.step()  # fills the device lr tensor in place: the next replay reads the new value
+    assert int(opt.state[next(model.parameters())]["step"]) == 6
+    for w, g_ in zip(want, got):
+        assert abs(w - g_) <= 2e-5 * abs(w), (want, got)
+    for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), n
