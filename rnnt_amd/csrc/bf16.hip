@@ -105,10 +105,11 @@ __device__ __forceinline__ void make_hidden_tile_bf16(const Bf16Args &a, long c_
         const f32x4 e0 = *(const f32x4 *)ep, e1 = *(const f32x4 *)(ep + 4);
         const f32x4 p0 = *(const f32x4 *)pp, p1 = *(const f32x4 *)(pp + 4);
         u32x4 o;
-        o[0] = pack_bf16(fast_tanh(e0[0] + p0[0]), fast_tanh(e0[1] + p0[1]));
-        o[1] = pack_bf16(fast_tanh(e0[2] + p0[2]), fast_tanh(e0[3] + p0[3]));
-        o[2] = pack_bf16(fast_tanh(e1[0] + p1[0]), fast_tanh(e1[1] + p1[1]));
-        o[3] = pack_bf16(fast_tanh(e1[2] + p1[2]), fast_tanh(e1[3] + p1[3]));
+        const f32x4 t0 = fast_tanh_sum4(e0, p0), t1 = fast_tanh_sum4(e1, p1);
+        o[0] = pack_bf16(t0[0], t0[1]);
+        o[1] = pack_bf16(t0[2], t0[3]);
+        o[2] = pack_bf16(t1[0], t1[1]);
+        o[3] = pack_bf16(t1[2], t1[3]);
         hid[c * H8 + h / 8] = o;
         u += rstep;
         while (u >= U1) { u -= U1; if (++t == T) { t = 0; ++b; } }

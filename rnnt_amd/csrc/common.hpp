@@ -39,12 +39,46 @@ __device__ __forceinline__ int len_u(const int32_t *target_lens, int b, int U1)
     return v < 0 ? 0 : (v > U1 - 1 ? U1 - 1 : v);
 }
 
+// Both lengths of utterance b (wave-uniform b) by two scalar loads issued together — one round trip
+// through the scalar cache instead of two serialised vector loads + readfirstlane at the head of a tile.
+// Kernels never write the length arrays, so the scalar cache cannot be stale within a launch.
+__device__ __forceinline__ void len_tu_uniform(const int32_t *logit_lens, const int32_t *target_lens, int b, int T, int U1,
+                                               int &Tb, int &Ub)
+{
+    int x, y;
+    const int32_t *pl = logit_lens + b, *pt = target_lens + b;
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y) : "s"(pl), "s"(pt) : "memory");
+    Tb = x < 1 ? 1 : (x > T ? T : x);
+    Ub = y < 0 ? 0 : (y > U1 - 1 ? U1 - 1 : y);
+}
+
 // tanh via one v_exp_f32 + one v_rcp_f32: 1 - 2/(exp(2x)+1).  Saturates correctly at
 // +-inf; absolute error <~3e-7 (the result feeds a dot product, absolute error matters).
 __device__ __forceinline__ float fast_tanh(float x)
 {
     float e = __builtin_amdgcn_exp2f(x * (2.0f * RNNT_LOG2E));
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// Two at a time on register pairs (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 around the two
+// transcendentals of each element): the same operations per element, bit for bit, in 4 + 4 issue slots
+// per pair instead of 6 + 4 — VALU instructions share the SIMD's issue port with the MFMA stream.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t fast_tanh2(f32x2_t x)
+{
+    const f32x2_t a = x * (2.0f * RNNT_LOG2E);
+    f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    e += 1.0f;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return 1.0f - 2.0f * r;
+}
+// tanh(e + p) for four consecutive elements
+__device__ __forceinline__ f32x4 fast_tanh_sum4(f32x4 e, f32x4 p)
+{
+    const f32x2_t lo = fast_tanh2(__builtin_shufflevector(e, e, 0, 1) + __builtin_shufflevector(p, p, 0, 1));
+    const f32x2_t hi = fast_tanh2(__builtin_shufflevector(e, e, 2, 3) + __builtin_shufflevector(p, p, 2, 3));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 // 32-lane (half-wave) butterfly reductions; xor masks < 32 never cross the wave halves,
@@ -77,21 +111,27 @@ __device__ __forceinline__ float half_bcast(float v, int half)
     const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
     return half ? hi : lo;
 }
+// The first four steps have the DPP operand fused into the max / add itself (hipcc keeps v_mov_b32_dpp +
+// the operation + a register copy apart: three VALU issue slots per step instead of one).  Inputs are
+// finite or -inf (max) / finite (sum): no NaN canonicalisation needed.  s_nop 1: the two wait states
+// between a VALU write and a DPP read of the same register, which the assembler does not add inside asm.
 __device__ __forceinline__ float half_max_dpp(float v, int half)
 {
-    v = fmaxf(v, dpp_mov<0xB1, 0xf>(v, v));
-    v = fmaxf(v, dpp_mov<0x4E, 0xf>(v, v));
-    v = fmaxf(v, dpp_mov<0x124, 0xf>(v, v));
-    v = fmaxf(v, dpp_mov<0x128, 0xf>(v, v));
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
     v = fmaxf(v, dpp_mov<0x142, 0xa>(RNNT_NEG_INF, v));
     return half_bcast(v, half);
 }
 __device__ __forceinline__ float half_sum_dpp(float v, int half)  // valid in lanes 16-31 / 48-63
 {
-    v += dpp_mov<0xB1, 0xf>(v, v);
-    v += dpp_mov<0x4E, 0xf>(v, v);
-    v += dpp_mov<0x124, 0xf>(v, v);
-    v += dpp_mov<0x128, 0xf>(v, v);
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
     v += dpp_mov<0x142, 0xa>(0.f, v);
     return v;
 }

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a, const in
     const int i = lane & 31, half = lane >> 5;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
     const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
-    const int Tb = len_t(a.logit_lens, b, a.T);
+    int Tb, Ub;  // both lengths by one pair of scalar loads (common.hpp)
+    len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub);
     const int t0 = tt * BT, u0 = ub * BU;
     const int VK = V / 8;
 
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a, const in
     const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : (long)a.B * T * U1;  // else zero row
     float *lptr = (float *)a.logits + pcell * V + 4 * half;
 
-    if (!GEN && (t0 >= Tb || u0 > len_u(a.target_lens, b, a.U1))) return;  // dead tile: no slab is read
+    if (!GEN && (t0 >= Tb || u0 > Ub)) return;  // dead tile: no slab is read
     if (t0 >= Tb) {  // workgroup-uniform: nothing to multiply, but k_dw must find zeros here
         // k_dw only walks the live rows, rounded out to 16-cell granules (k_dw_table): up to 15
         // cells past this utterance's live end, and up to 15 cells before the next utterance's
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_gen(JointBwdArgs a, const in
         }
         return;
     }
-    if (u0 > len_u(a.target_lens, b, a.U1)) {  // workgroup-uniform: a u block past U_b holds no lattice cell — its G
+    if (u0 > Ub) {  // workgroup-uniform: a u block past U_b holds no lattice cell — its G
         if (pexists) {  // rows are zeros (k_dw walks them), its slabs are never read
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             for (int c8 = 0; c8 < VK; ++c8) *(f32x4 *)(lptr + 8 * c8) = z;

@@ -444,11 +444,12 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
     const int b = by_;
     const int m0 = bx_ * FWD_ROWS;
     const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
-    const int Tb = WITH_LOSS ? len_t(a.logit_lens, b, a.T) : T;
+    int Tb = T, Ub_ = U1 - 1;
+    if (WITH_LOSS) len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub_);
     // Rows of the GEMM = the utterance's LIVE cells only, in (t, u <= U_b) order: compact index m is
     // cell (t = m / W1, u = m % W1), W1 = U_b + 1 live columns, stored at its natural row t*U1 + u of
     // the [cells] buffers.  A ragged batch costs its live cells; a full one (W1 == U1) is unchanged.
-    const int W1 = WITH_LOSS ? len_u(a.target_lens, b, a.U1) + 1 : U1;
+    const int W1 = Ub_ + 1;
     const int ncell = Tb * W1;
     // Two workgroups share every SIMD of the CU.  A wave in one of its short non-MFMA phases (hidden
     // production, pass epilogue, finalisation) issues at priority 1, a wave in its main loop at 0: the
@@ -498,9 +499,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                     const int r = wave + i * NW;
                     const f32x4 e = r >= cut ? e1 : e0;  // wave-uniform
                     const int tr = r >= cut ? t_first + 1 : t_first;
-                    f32x4 o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[q] + p[i][q]);
+                    const f32x4 o = fast_tanh_sum4(e, p[i]);
                     if (r < nrow) *(f32x4 *)(hidb + ((long)tr * U1 + (m0 + r - tr * W1)) * H + h) = o;
                 }
             }
@@ -522,9 +521,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                         const int r = wave + (rb + i) * NW;
                         const int c = m0 + r;
                         const int t = c / W1, u = c - t * W1;
-                        f32x4 o;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = fast_tanh(e[i][q] + p[i][q]);
+                        const f32x4 o = fast_tanh_sum4(e[i], p[i]);
                         if (r < nrow) *(f32x4 *)(hidb + ((long)t * U1 + u) * H + h) = o;
                     }
                 }
@@ -546,7 +543,7 @@ __device__ __forceinline__ void fwd_tile(const JointFwdArgs &a, const int bx_, c
                 ((unsigned long long)xcc << 32) | hw;
     }
 #endif
-    const int Ub = WITH_LOSS ? len_u(a.target_lens, b, a.U1) : U1 - 1;
+    const int Ub = Ub_;
 
     // per-lane running (max, sum-exp) of the 16 accumulator rows this lane sees, parked in LDS
     // between passes (slot [r][tid]: conflict-free) so it costs no VGPRs in the main loop;
