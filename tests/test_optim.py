@@ -1,7 +1,6 @@
 """-m gpu: rnnt_amd.optim (C ABI rnnt_engine_grad_norm / rnnt_engine_adamw_step) against
 torch.nn.utils.clip_grad_norm_ and torch.optim.AdamW — the statements at reference
 rnnt/train.py:136,164 with the hyper-parameters of rnnt/config/basic_sp_convjs_fullcausal.yaml:80-87."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """CPU tests: the oracle (oracle/rnnt_oracle.c) against the golden vectors produced from the
 reference's own JointNetwork, brute-force alignment enumeration and torch autograd."""
-import glob
 import os
 
 import numpy as np
