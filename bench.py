@@ -288,6 +288,7 @@ def main():
         # what actually ran: devices the runtime sees, ranks in the RCCL communicator
         "hipGetDeviceCount": torch.cuda.device_count(),
         "rccl_ranks": dist.get_world_size() if dist_on else 0,
+        "dist_backend": (("rccl" if backend == "nccl" else backend) if dist_on else None),  # "nccl" is RCCL on ROCm; gloo only in rehearsals
         "allreduce_via": ("rnnt_engine_allreduce" if comm is not None else "torch.distributed") if dist_on else None,
     }
     flops_cell = 6.0 * H * V  # 2HV fwd + 2HV dHidden + 2HV dW per lattice cell
