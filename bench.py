@@ -117,8 +117,12 @@ def parity_twin(H, V, device, dtype="fp32"):
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N rank
     processes here, one per GPU — the process layout of reference rnnt/train.py:25-33 (mp.spawn,
-    one rank per device, "nccl").  The parent never touches the GPU (device_count() does not
-    initialise HIP); it refuses to run fewer ranks than asked for."""
+    one rank per device, "nccl").  The parent launches no GPU work: the ranks are FRESH child processes
+    (Popen, never a re-exec of this one), so whatever torch.cuda.device_count() does to count the devices
+    stays in the parent; it refuses to run fewer ranks than asked for.  A parent that is told to stop
+    (SIGTERM / SIGINT, e.g. the driver's timeout) takes its ranks with it — none is left blocked in a
+    collective holding a GPU and the rendezvous port."""
+    import signal
     import socket
     import subprocess
     have = torch.cuda.device_count()
@@ -133,24 +137,46 @@ def self_launch(n):
     port = sock.getsockname()[1]
     sock.close()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def stop_ranks(grace=5.0):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + grace
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def on_signal(signum, _frame):
+        stop_ranks()
+        raise SystemExit(128 + signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = list(procs)
-    while live:  # a rank that dies would leave the others waiting in a collective: stop them
-        time.sleep(0.2)
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in live:
-                    q.terminate()
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        live = list(procs)
+        while live:  # a rank that dies would leave the others waiting in a collective: stop them
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:
+                        q.terminate()
+    finally:  # whatever ends this loop (a signal, an exception): no rank outlives the parent
+        stop_ranks()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     raise SystemExit(rc)
 
 

@@ -13,12 +13,68 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_CSRC, "librnnt_engine.so")
+# RNNT_ENGINE_LIB: another BUILD of the same engine (a diagnostic -DRNNT_ABLATE / -DRNNT_STAMPS library of
+# tools/exp_*.py, an A/B candidate).  Still the HIP engine and nothing else: a missing file raises.
+LIB_PATH = os.environ.get("RNNT_ENGINE_LIB") or os.path.join(_CSRC, "librnnt_engine.so")
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1  # bf16 GEMM operands, fp32 accumulate, fp16 logits (workspace), fp32/fp64 loss; fp32 tensors at the boundary
 _DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, DTYPE_F32: DTYPE_F32,
            "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, DTYPE_BF16: DTYPE_BF16}
+
+
+class _Int32:
+    """argtypes entry for a C `int`: ctypes' own c_int wraps silently (2**31 -> -2**31) and a dimension
+    that does not fit must raise, as must a float where a dimension is expected."""
+
+    @classmethod
+    def from_param(cls, v):
+        if isinstance(v, ctypes.c_int):
+            return v
+        if isinstance(v, bool) or not isinstance(v, int):
+            raise TypeError(f"rnnt_engine: C int argument needs a Python int, got {type(v).__name__} ({v!r})")
+        if not -2 ** 31 <= v < 2 ** 31:
+            raise OverflowError(f"rnnt_engine: {v} does not fit a C int")
+        return ctypes.c_int(v)
+
+
+# Argument kinds of every entry point of include/rnnt_engine.h, in declaration order (i = int,
+# q = int64_t, z = size_t, f = float, d = double, p = any pointer).  tests/test_abi.py re-derives this
+# table from the header, so a prototype change that is not mirrored here fails on the CPU.
+_KINDS = {"i": _Int32, "q": ctypes.c_int64, "z": ctypes.c_size_t, "f": ctypes.c_float,
+          "d": ctypes.c_double, "p": ctypes.c_void_p}
+SIGNATURES = {
+    "rnnt_engine_version": "",
+    "rnnt_engine_set_flags": "i",
+    "rnnt_engine_set_debug": "p",
+    "rnnt_engine_debug_query": "i",
+    "rnnt_engine_last_error": "",
+    "rnnt_engine_workspace_bytes": "iiiiiip",
+    "rnnt_engine_loss_workspace_bytes": "iiiiip",
+    "rnnt_engine_joint_fwd_workspace_bytes": "iiiiiip",
+    "rnnt_engine_joint_fwd": "pppppiiiiiippzp",
+    "rnnt_engine_loss_fwd_bwd": "ppppiiiiifipppzp",
+    "rnnt_engine_joint_loss_fwd_bwd": "ppppppppiiiiiiffippppppzp",
+    "rnnt_engine_joint_loss_fwd": "ppppppppiiiiiiippzp",
+    "rnnt_engine_joint_bwd_workspace_bytes": "iiiiiip",
+    "rnnt_engine_joint_bwd": "pppppiiiiiipppppzp",
+    "rnnt_engine_greedy_scan_workspace_bytes": "iiip",
+    "rnnt_engine_greedy_scan": "pqqpppiiiiippzp",
+    "rnnt_engine_grad_norm_workspace_bytes": "ipp",
+    "rnnt_engine_grad_norm": "ippppzp",
+    "rnnt_engine_adamw_step": "ipppppdddddqpfip",
+    "rnnt_engine_adamw_step_dev": "ippppppddddpppfip",
+    "rnnt_engine_conv_predictor_saved_bytes": "iiiiip",
+    "rnnt_engine_conv_predictor_fwd": "piiiiipppffppzp",
+    "rnnt_engine_conv_predictor_bwd": "piiiiipppfpppzp",
+    "rnnt_engine_linear_fwd": "pqppiiipp",
+    "rnnt_engine_linear_bwd_workspace_bytes": "iiip",
+    "rnnt_engine_linear_bwd": "pqppiiippppzp",
+    "rnnt_engine_allreduce": "pzpp",
+    "rnnt_engine_workspace_layout": "iiiiiip",
+    "rnnt_engine_run_stage": "ippppppppiiiiiiffippppppzp",
+    "rnnt_engine_run_stages": "iippppppppiiiiiiffippppppzp",
+}
 
 
 def dtype_code(dtype):
@@ -31,6 +87,7 @@ def dtype_code(dtype):
 _lock = threading.Lock()
 _lib = None
 _workspaces = {}
+_captured = {}  # (device, stream) -> workspace a captured HIP graph points into: never freed or replaced
 
 EXPORTS = (
     "rnnt_engine_version", "rnnt_engine_last_error", "rnnt_engine_workspace_bytes",
@@ -83,10 +140,15 @@ def lib():
                     "`python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950). There is no CPU/torch fallback.")
             L = ctypes.CDLL(LIB_PATH)
-            L.rnnt_engine_last_error.restype = ctypes.c_char_p
             for name in EXPORTS:
                 if not hasattr(L, name):
                     raise RuntimeError(f"rnnt_amd: {LIB_PATH} does not export {name}")
+            for name, kinds in SIGNATURES.items():  # typed bindings: a wrong kind or an int beyond 2^31 raises
+                fn = getattr(L, name)
+                fn.argtypes = [_KINDS[k] for k in kinds]
+                fn.restype = ctypes.c_int
+            L.rnnt_engine_last_error.restype = ctypes.c_char_p
+            L.rnnt_engine_set_debug.restype = None
             _lib = L
     return _lib
 
@@ -145,20 +207,36 @@ def _require_contiguous(**tensors):
 
 def workspace(device, nbytes):
     """Grow-only scratch buffer per (device, stream): work enqueued on two streams of one device
-    never shares scratch memory (torch owns the memory; 256-byte aligned)."""
+    never shares scratch memory (torch owns the memory; 256-byte aligned).
+
+    HIP graphs: a call captured by `torch.cuda.graph` has this buffer's address baked into its
+    kernel arguments.  A buffer handed out during a capture is therefore PINNED: it is never
+    replaced (growth on that stream raises instead of freeing memory a graph still replays into)
+    and `release_workspaces()` keeps it alive — INTEGRATION.md "HIP graphs"."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (device.type, idx, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None or ws.numel() < nbytes:
+        if key in _captured:
+            raise RuntimeError(
+                f"rnnt_amd: this stream's workspace ({ws.numel()} B) is baked into a captured HIP graph and the "
+                f"call needs {int(nbytes)} B; warm up with the largest shapes before capturing "
+                "(rnnt_amd.engine.workspace)")
         _workspaces.pop(key, None)
         ws = None
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+    if capturing:
+        _captured[key] = ws
     return ws
 
 
 def release_workspaces():
-    _workspaces.clear()
+    """Drop the cached scratch buffers — except those a captured HIP graph points into."""
+    for key in list(_workspaces):
+        if key not in _captured:
+            del _workspaces[key]
 
 
 def layout(B, T, U1, H, V, dtype="fp32"):

@@ -155,19 +155,43 @@ class AdamW(torch.optim.Optimizer):
                         engine._stream(dev)))
         return loss
 
+    def _state_step(self, ps):
+        """Step count the (loaded or running) state of `ps` carries: int, or tensor from torch's own AdamW."""
+        step0 = 0
+        for p in ps:
+            st = self.state.get(p, {})
+            if "step" in st:
+                step0 = max(step0, int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"]))
+        return step0
+
+    def _seed_dev(self, gi, ps, dev):
+        """The group's device step counter and scratch, created once (a captured graph points at them)
+        from whatever count the state holds."""
+        if gi not in self._dev:
+            self._dev[gi] = (torch.full((1,), self._state_step(ps), dtype=torch.int64, device=dev),
+                             torch.zeros(4, dtype=torch.float32, device=dev))
+        return self._dev[gi]
+
+    def load_state_dict(self, state_dict):
+        """A resume (the reference's checkpoints, rnnt/util.py:7-24) after the first step: the device
+        counter of every group continues from the LOADED count and the loaded learning rate lands in the
+        device lr tensor — both updated IN PLACE, so a captured graph that points at them stays valid and
+        the loaded per-parameter step values are not overwritten by the pre-load counter."""
+        old_lr = [g["lr"] for g in self.param_groups]
+        super().load_state_dict(state_dict)
+        for gi, group in enumerate(self.param_groups):
+            if torch.is_tensor(old_lr[gi]) and self.capturable:
+                new = group["lr"]
+                old_lr[gi].fill_(float(new.item()) if torch.is_tensor(new) else float(new))
+                group["lr"] = old_lr[gi]
+            if gi in self._dev:
+                self._dev[gi][0].fill_(self._state_step(group["params"]))
+
     def _step_capturable(self, lib, gi, group, ps, gs, dev, total):
         if len(ps) != len(group["params"]):
             raise RuntimeError("rnnt_amd.optim.AdamW(capturable=True): every parameter of a group needs a gradient "
                                "each step (one device step counter per group)")
-        if gi not in self._dev:
-            step0 = 0
-            for p in ps:  # a loaded checkpoint carries the count (int, or tensor from torch's own AdamW)
-                st = self.state[p]
-                if "step" in st:
-                    step0 = max(step0, int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"]))
-            self._dev[gi] = (torch.full((1,), step0, dtype=torch.int64, device=dev),
-                             torch.zeros(4, dtype=torch.float32, device=dev))
-        step_dev, hyper = self._dev[gi]
+        step_dev, hyper = self._seed_dev(gi, ps, dev)
         lr = group["lr"]
         if not torch.is_tensor(lr):
             lr = group["lr"] = torch.tensor(float(lr), dtype=torch.float32, device=dev)

@@ -119,3 +119,76 @@ def test_allreduce_entry_validation(lib):
     lib.rnnt_engine_last_error.restype = ctypes.c_char_p
     assert lib.rnnt_engine_allreduce(None, ctypes.c_size_t(8), None, None) == -1
     assert b"null" in lib.rnnt_engine_last_error()
+
+
+def _header_signatures():
+    """{name: kinds} from the prototypes of include/rnnt_engine.h (i int, q int64_t, z size_t, f float,
+    d double, p pointer / array)."""
+    text = open(os.path.join(ROOT, "include", "rnnt_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = re.findall(r"(?:^|\n)\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(rnnt_engine_\w+)\s*\(([^;{]*?)\)\s*;",
+                        text, flags=re.S)
+    scalar = {"int": "i", "int32_t": "i", "int64_t": "q", "size_t": "z", "float": "f", "double": "d"}
+    out = {}
+    for name, args in protos:
+        kinds = ""
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if a == "void":
+                continue
+            if "*" in a or "[" in a:
+                kinds += "p"
+            else:
+                words = a.replace("const ", "").split()
+                kinds += scalar[" ".join(words[:-1]) if len(words) > 1 else words[0]]
+        out[name] = kinds
+    return out
+
+
+def test_ctypes_signatures_match_the_header(lib):
+    """Every declared entry point has typed ctypes bindings, and the table in rnnt_amd/engine.py is the
+    header's prototypes (argument count and kind), so a prototype edit cannot drift silently."""
+    from rnnt_amd import engine
+    hdr = _header_signatures()
+    assert set(hdr) == set(_declared_symbols())
+    assert engine.SIGNATURES == hdr
+    for name, kinds in hdr.items():
+        assert len(getattr(lib, name).argtypes) == len(kinds), name
+
+
+def test_typed_bindings_reject_bad_scalars(lib):
+    """a dimension passed as a non-int, or beyond 2^31, raises instead of being truncated."""
+    n = ctypes.c_size_t(0)
+    with pytest.raises(ctypes.ArgumentError):
+        lib.rnnt_engine_workspace_bytes(2.0, 5, 3, 16, 8, 0, ctypes.byref(n))
+    with pytest.raises(ctypes.ArgumentError):
+        lib.rnnt_engine_workspace_bytes(2 ** 31 + 2, 5, 3, 16, 8, 0, ctypes.byref(n))
+    with pytest.raises(ctypes.ArgumentError):
+        lib.rnnt_engine_workspace_bytes(True, 5, 3, 16, 8, 0, ctypes.byref(n))
+    with pytest.raises(ctypes.ArgumentError):
+        lib.rnnt_engine_workspace_bytes(2, 5, 3, 16, 8, 0, 3.5)  # not a pointer
+    with pytest.raises(TypeError):  # too few arguments
+        lib.rnnt_engine_workspace_bytes(2, 5, 3, 16, 8, 0)
+    assert lib.rnnt_engine_workspace_bytes(2, 5, 3, 16, 8, 0, ctypes.byref(n)) == 0
+
+
+def test_engine_sources_only_enqueue_kernels():
+    """The library's contract (include/rnnt_engine.h: "every call only ENQUEUES work on `stream`", no
+    allocation, no synchronisation) and the HIP-graph rule of DESIGN.md §3 (a captured call is a chain of
+    KERNEL nodes: fills and copies are kernels, never memset/memcpy nodes) as a source check: none of these
+    runtime calls may appear in rnnt_amd/csrc outside comments."""
+    banned = re.compile(r"\bhip(MemsetAsync|Memset|MemcpyAsync|Memcpy|Memcpy2D\w*|DeviceSynchronize|StreamSynchronize|"
+                        r"EventSynchronize|Malloc\w*|Free\w*|HostMalloc|StreamCreate\w*|GraphLaunch)\s*\(")
+    csrc = os.path.join(ROOT, "rnnt_amd", "csrc")
+    hits = []
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".hpp", ".h", ".cpp")):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        text = re.sub(r"/\*.*?\*/", lambda m: "\n" * m.group(0).count("\n"), text, flags=re.S)
+        for ln, line in enumerate(text.splitlines(), 1):
+            code = line.split("//", 1)[0]
+            if banned.search(code):
+                hits.append(f"{fn}:{ln}: {line.strip()}")
+    assert not hits, "runtime calls the engine must not make:\n" + "\n".join(hits)

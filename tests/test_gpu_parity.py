@@ -528,6 +528,49 @@ def test_bad_lengths_are_clamped_on_the_device(amd):
     dc["target_lens"] = np.array([70, 0, 70], dtype=np.int32)
     ref = oracle_fused(dc)
     assert_close_loss("costs", costs.cpu().numpy(), ref["costs"])
+    # ... and the GRADIENTS are those of the clamped lattice (every backward kernel reads the same clamped
+    # lengths: dead tiles skipped, dead rows zero), on both arithmetic routes that share the lattice code
+    outs = amd.engine.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"],
+                                         g["target_lens"], 31, 1.0 / 3)
+    torch.cuda.synchronize()
+    assert_close_loss("costs", outs[0].cpu().numpy(), ref["costs"])
+    for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")):
+        assert_close_grad(k, o.cpu().numpy(), ref[k])
+    # utterance 1 was clamped to U_b = 0, utterance 2 to T_b = 1: nothing outside those lattices has a gradient
+    assert float(outs[2][1, 1:].abs().max()) == 0.0 and float(outs[1][2, 1:].abs().max()) == 0.0
+    db = make_inputs(3, 20, 70, 128, 128, seed=10)
+    db["logit_lens"], db["target_lens"] = d["logit_lens"], d["target_lens"]
+    gb = _dev(db)
+    outs = amd.engine.joint_loss_fwd_bwd(gb["enc"], gb["pred"], gb["W"], gb["bias"], gb["targets"], gb["logit_lens"],
+                                         gb["target_lens"], 127, 1.0 / 3, dtype="bf16")
+    torch.cuda.synchronize()
+    dbc = dict(db)
+    dbc["logit_lens"], dbc["target_lens"] = dc["logit_lens"], dc["target_lens"]
+    refb = oracle_fused_bf16(dbc)
+    assert_close_loss("costs", outs[0].cpu().numpy(), refb["costs"], rtol=BF16_LOSS_RTOL)
+    for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")):
+        assert_close_grad(k, o.cpu().numpy(), refb[k], rtol=BF16_GRAD_RTOL)
+
+
+def test_inputs_ending_at_unmapped_pages():
+    """Input OVER-READS (the class of the round-2 bf16 fault: a bias read 512 B past the vector at V = 128,
+    commit 1f6212f — invisible to every parity test because the neighbouring allocation was mapped): every
+    input of the fused call placed so that it ends at an unmapped page (HIP virtual-memory API,
+    tools/guard_alloc.hip) for 9 fused shapes on both routes — V = 128 bf16 and H = 1024 among them — plus one
+    call of every other entry point.  Runs tools/guard_sweep.py --slice in a CHILD process: a memory fault
+    kills the child and fails this test, the rest of the run goes on.  Run once; never looped."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tools", "libguard.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-o", so,
+                               os.path.join(root, "tools", "guard_alloc.hip")])
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "guard_sweep.py"), "--slice"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    tail = (out.stdout[-1500:] + "\n" + out.stderr[-1500:])
+    assert out.returncode == 0, "guard sweep died (memory fault = an input over-read):\n" + tail
+    assert "guard sweep clean: 9 cases" in out.stdout and "guard sweep of the other entry points clean" in out.stdout, tail
 
 
 # ---------------------------------------------------------------- full-size properties
@@ -718,6 +761,68 @@ def test_greedy_decode_scan_matches_per_frame_loop(amd):
         assert model.greedy_decode(mel, lens, max_length=80, scan_frames=128) == b
 
 
+def test_greedy_decode_stateful_predictor_branch(amd):
+    """RNNTModel.greedy_decode with a STATEFUL predictor — forward(ids, lens, state=None) ->
+    (features, lens, state), fed the last token only (reference rnnt/model.py:45-87, the LSTMPredictor
+    branch): a running-sum stand-in whose state is its last output decodes exactly what the stateless
+    predictor computing the same prefix sums from the whole token list does, scan and per-frame loop alike."""
+    torch.manual_seed(11)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv1d(10, 24, 3, stride=2, padding=1)
+
+        def forward(self, x):
+            return self.c(x)
+
+        def calc_output_lens(self, lens):
+            return (lens + 1) // 2
+
+    class Stateless(torch.nn.Module):
+        def __init__(self, emb):
+            super().__init__()
+            self.e = emb
+
+        def forward(self, ids):
+            return torch.cumsum(self.e(ids), dim=1)
+
+    class Stateful(torch.nn.Module):
+        def __init__(self, emb):
+            super().__init__()
+            self.e = emb
+            self.calls = []
+
+        def forward(self, ids, lens, state=None):
+            self.calls.append((ids.shape[1], state is not None))
+            f = torch.cumsum(self.e(ids), dim=1)
+            if state is not None:
+                f = f + state
+            return f, lens, f[:, -1:, :]
+
+    emb = torch.nn.Embedding(16, 24)
+    with torch.no_grad():
+        emb.weight.mul_(0.3)
+    joint = amd.JointNetwork(-1, -1, 24, 16)
+    enc = Enc()
+    ref_model = amd.RNNTModel(Stateless(emb), enc, joint).cuda()
+    sf = Stateful(emb)
+    model = amd.RNNTModel(sf, enc, joint).cuda()
+    assert model._predictor_is_stateful() and not ref_model._predictor_is_stateful()
+    with torch.no_grad():
+        joint.joint_ln.bias[15] += 1.0
+    mel = torch.randn(1, 10, 120, device="cuda")
+    lens = torch.tensor([120], device="cuda")
+    want = ref_model.greedy_decode(mel, lens, max_length=60, scan_frames=0)
+    assert 0 < len(want) <= 59
+    for scan in (16, 0, 128):
+        sf.calls.clear()
+        assert model.greedy_decode(mel, lens, max_length=60, scan_frames=scan) == want
+        # first call: the start blank without a state; afterwards ONE token at a time with the state
+        assert sf.calls[0] == (1, False) and all(c == (1, True) for c in sf.calls[1:])
+        assert len(sf.calls) == len(want) + 1
+
+
 def _bf16_vs_fp32_fullsize(amd, B, T, U, H, V, seed):
     """Full-size ragged inputs through both routes: every bf16 kernel at BASELINE sizes (row
     offsets beyond 2^31 bytes, all tiles / passes / splits), held to bf16's error of the fp32 route."""
@@ -793,7 +898,8 @@ def _fused_outs(amd, g, outs=None, dtype="fp32"):
                                          ("fp32", (2, 30, 9, 1024, 256)), ("bf16", (3, 40, 12, 256, 512)),
                                          ("bf16", (2, 30, 9, 1024, 256))])
 def test_fused_call_is_hip_graph_capturable(amd, dtype, shape):
-    """The C-ABI call enqueues kernels and async memsets on the caller's stream and nothing else (no
+    """The C-ABI call enqueues KERNELS on the caller's stream and nothing else (no memset / memcpy nodes —
+    fills and copies are kernels too, tests/test_abi.py::test_engine_sources_only_enqueue_kernels — no
     allocation, no synchronisation, no host read-back): it can be captured into a HIP graph and
     replayed.  The replay reads its inputs at replay time — new contents in the same buffers give the
     new answer, bit for bit what the eager call gives."""

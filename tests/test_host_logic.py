@@ -172,3 +172,64 @@ def test_overlay_package_swaps_joint_and_model_only():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "integration"), root, "/root/reference"]))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "overlay ok" in out.stdout, out.stderr[-1500:]
+
+
+def test_capturable_adamw_resume_keeps_the_loaded_step_count():
+    """AdamW(capturable=True).load_state_dict after the first step — the device step counter
+    continues from the LOADED count (not the pre-load one), in place, and the loaded learning rate lands
+    in the tensor a captured graph points at.  Host logic only: no engine call, CPU tensors."""
+    import torch
+    from rnnt_amd.optim import AdamW
+    ps = [torch.zeros(4, requires_grad=True), torch.zeros(3, requires_grad=True)]
+    opt = AdamW(ps, lr=1e-3, capturable=True)
+    for p in ps:
+        opt.state[p].update(step=torch.tensor(5.0), exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+    step_dev, _ = opt._seed_dev(0, ps, torch.device("cpu"))
+    assert int(step_dev) == 5
+    lr_dev = torch.tensor(1e-3)
+    opt.param_groups[0]["lr"] = lr_dev
+    for p in ps:
+        opt.state[p]["step"] = step_dev  # what _step_capturable does: one shared counter
+    sd = opt.state_dict()
+    for st in sd["state"].values():
+        st["step"] = torch.tensor(12.0)  # a checkpoint written 7 steps later
+    sd["param_groups"][0]["lr"] = 2.5e-4
+    opt.load_state_dict(sd)
+    assert opt._dev[0][0] is step_dev and int(step_dev) == 12       # same tensor, loaded count
+    assert opt.param_groups[0]["lr"] is lr_dev and abs(float(lr_dev) - 2.5e-4) < 1e-10
+    assert opt._state_step(ps) == 12
+    # a fresh optimizer that loads before its first step seeds its counter from the loaded state
+    opt2 = AdamW([torch.zeros(4, requires_grad=True), torch.zeros(3, requires_grad=True)], lr=1e-3, capturable=True)
+    opt2.load_state_dict(sd)
+    assert int(opt2._seed_dev(0, opt2.param_groups[0]["params"], torch.device("cpu"))[0]) == 12
+
+
+def test_workspace_of_a_captured_graph_is_pinned(monkeypatch):
+    """a workspace handed out while the stream is capturing is baked into the graph's kernel
+    arguments — it must never be replaced (growth raises) or dropped by release_workspaces()."""
+    import torch
+    from rnnt_amd import engine
+    monkeypatch.setattr(engine, "_workspaces", {})
+    monkeypatch.setattr(engine, "_captured", {})
+    state = {"capturing": False}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: state["capturing"])
+
+    class _S:
+        cuda_stream = 7
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: _S())
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda n, dtype=None, device=None: real_empty(n, dtype=dtype))
+    dev = torch.device("cuda", 0)
+    a = engine.workspace(dev, 100)
+    assert engine.workspace(dev, 50) is a            # grow-only cache
+    b = engine.workspace(dev, 200)                   # not captured yet: growth replaces
+    assert b is not a and b.numel() == 200
+    state["capturing"] = True
+    assert engine.workspace(dev, 150) is b           # handed out under capture -> pinned
+    state["capturing"] = False
+    engine.release_workspaces()
+    assert engine.workspace(dev, 10) is b            # still there after a release
+    import pytest
+    with pytest.raises(RuntimeError, match="captured HIP graph"):
+        engine.workspace(dev, 400)

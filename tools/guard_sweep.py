@@ -2,7 +2,9 @@
 an unmapped page (tools/guard_alloc.hip, HIP virtual-memory API): a kernel that reads past the end of an
 input faults instead of silently reading a neighbouring allocation.  Prints one line per case; a memory
 access fault aborts the process (the case printed last + the ranges printed for it name the culprit).
-   hipcc -shared -fPIC -o tools/libguard.so tools/guard_alloc.hip && python tools/guard_sweep.py"""
+   hipcc -shared -fPIC -o tools/libguard.so tools/guard_alloc.hip && python tools/guard_sweep.py
+`--slice` runs the subset tests/test_gpu_parity.py::test_inputs_ending_at_unmapped_pages executes in a child
+process under `pytest -m gpu` (a fault kills the child, not the test run)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -11,6 +13,7 @@ import torch
 import rnnt_amd as amd
 from helpers import make_inputs, oracle_fused, oracle_fused_bf16, assert_close_loss, BF16_LOSS_RTOL
 
+SLICE = "--slice" in sys.argv[1:]
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libguard.so"))
 torch.cuda.init(); torch.zeros(1, device="cuda")
 
@@ -39,6 +42,12 @@ CASES = [("fp32", s) for s in [(1, 1, 0, 8, 4), (2, 5, 2, 16, 8), (3, 23, 19, 36
                                (2, 30, 9, 1024, 260), (3, 37, 11, 128, 132), (2, 50, 101, 512, 1024), (2, 130, 50, 512, 256)]] + \
         [("bf16", s) for s in [(1, 1, 0, 128, 128), (2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024),
                                (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128), (1, 43, 27, 256, 128), (2, 50, 101, 512, 1024)]]
+if SLICE:  # includes the case of commit 1f6212f (bf16, V = 128: a bias read past the vector) and the reference's H = 1024
+    CASES = [("fp32", (2, 5, 2, 16, 8)), ("fp32", (3, 23, 19, 36, 132)), ("fp32", (3, 21, 18, 1024, 64)),
+             ("fp32", (2, 9, 4, 516, 96)), ("fp32", (2, 30, 9, 1024, 260)), ("bf16", (2, 9, 4, 128, 128)),
+             ("bf16", (1, 43, 27, 256, 128)), ("bf16", (2, 13, 20, 1024, 256)), ("bf16", (3, 21, 9, 640, 128))]
+    if "--x3" in sys.argv[1:]:
+        CASES += [("bf16x3", (2, 9, 4, 128, 128)), ("bf16x3", (2, 13, 20, 1024, 256)), ("bf16x3", (3, 21, 9, 640, 128))]
 for dtype, (B, T, U, H, V) in CASES:
     d = make_inputs(B, T, U, H, V, seed=B + T + U + H + V)
     g, ranges = {}, {}
@@ -50,6 +59,8 @@ for dtype, (B, T, U, H, V) in CASES:
     torch.cuda.synchronize()
     ref = oracle_fused_bf16(d) if dtype == "bf16" else oracle_fused(d)
     assert_close_loss("costs", outs[0].cpu().numpy(), ref["costs"], rtol=BF16_LOSS_RTOL if dtype == "bf16" else 1e-4)
+    for o in outs[1:]:  # gradients finite: an over-read that lands on mapped memory still shows as garbage
+        assert bool(torch.isfinite(o).all())
     print("   ok", flush=True)
 print("guard sweep clean:", len(CASES), "cases")
 
@@ -57,7 +68,7 @@ print("guard sweep clean:", len(CASES), "cases")
 # greedy-decode scan — inputs again end at unmapped pages
 rng = np.random.default_rng(5)
 G = lambda a: guarded(np.ascontiguousarray(a))[0]
-for (B, T, U, H, V) in [(2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 13, 6, 640, 1024), (2, 40, 33, 72, 520), (1, 64, 40, 32, 1300)]:
+for (B, T, U, H, V) in [(3, 23, 19, 36, 132)] if SLICE else [(2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 13, 6, 640, 1024), (2, 40, 33, 72, 520), (1, 64, 40, 32, 1300)]:
     d = make_inputs(B, T, U, H, V, seed=1 + H + V)
     enc, pred, W, bias = G(d["enc"]), G(d["pred"]), G(d["W"]), G(d["bias"])
     logits = amd.engine.joint_fwd(enc, pred, W, bias)
@@ -68,13 +79,13 @@ for (B, T, U, H, V) in [(2, 9, 4, 20, 12), (3, 23, 19, 36, 132), (2, 13, 6, 640,
     amd.engine.joint_loss_fwd(enc, pred, W, bias, G(d["targets"]), G(d["logit_lens"]), G(d["target_lens"]), V - 1)
     torch.cuda.synchronize()
     print(f"unfused entries ok B={B} T={T} U={U} H={H} V={V}", flush=True)
-for (M, K, N) in [(7, 12, 8), (250, 96, 256), (1000, 1024, 1024), (33, 516, 260), (3000, 256, 1024)]:
+for (M, K, N) in [(33, 516, 260)] if SLICE else [(7, 12, 8), (250, 96, 256), (1000, 1024, 1024), (33, 516, 260), (3000, 256, 1024)]:
     x, Wl, bl = G(rng.standard_normal((M, K)).astype(np.float32)), G(rng.standard_normal((N, K)).astype(np.float32)), G(rng.standard_normal(N).astype(np.float32))
     y = amd.engine.linear_fwd(x, Wl, bl)
     amd.engine.linear_bwd(x, Wl, G(rng.standard_normal((M, N)).astype(np.float32)))
     torch.cuda.synchronize()
     print(f"linear ok M={M} K={K} N={N}", flush=True)
-for (S, O, E, B, U1) in [(17, 24, 12, 2, 5), (64, 96, 128, 3, 31), (1024, 1024, 512, 4, 101), (33, 260, 36, 1, 1)]:
+for (S, O, E, B, U1) in [(64, 96, 128, 3, 31)] if SLICE else [(17, 24, 12, 2, 5), (64, 96, 128, 3, 31), (1024, 1024, 512, 4, 101), (33, 260, 36, 1, 1)]:
     m = amd.ConvPredictor(S, O, E, dropout=0.25).cuda().train()
     with torch.no_grad():
         for p in m.parameters():  # parameters themselves against unmapped pages
@@ -84,7 +95,7 @@ for (S, O, E, B, U1) in [(17, 24, 12, 2, 5), (64, 96, 128, 3, 31), (1024, 1024, 
     out.backward(G(rng.standard_normal(tuple(out.shape)).astype(np.float32)))
     torch.cuda.synchronize()
     print(f"ConvPredictor ok S={S} O={O} E={E} B={B} U1={U1}", flush=True)
-for (T, H, V, n) in [(50, 512, 1024, 32), (7, 64, 128, 7), (130, 1024, 1024, 128)]:
+for (T, H, V, n) in [(50, 512, 1024, 32)] if SLICE else [(50, 512, 1024, 32), (7, 64, 128, 7), (130, 1024, 1024, 128)]:
     enc1, pr1 = G(rng.standard_normal((T, H)).astype(np.float32)), G(rng.standard_normal(H).astype(np.float32))
     W1, b1 = G((rng.standard_normal((V, H)) / np.sqrt(H)).astype(np.float32)), G(rng.standard_normal(V).astype(np.float32))
     for t0 in (0, max(0, T - n)):
