@@ -41,29 +41,36 @@ CONFIGS = {
     "ref512b": (32, 500, 103, 512, 1024),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"; bf16x3 spends 6 bf16 products per fp32 product
 PEAK_HBM_GBS = 8000.0
 
 
-def synth(B, T, U, H, V, seed, device):
+def synth(B, T, U, H, V, seed, device, permuted_enc=False):
     """Synthetic inputs of SURVEY.md §8d: unit-scale enc/pred, torch-Linear-default W/bias,
-    targets uniform in [0,V-2], all lengths full so B*T*U is exact work."""
+    targets uniform in [0,V-2], all lengths full so B*T*U is exact work.  permuted_enc: `enc` is the
+    view the reference really hands over — `.permute(0, 2, 1)` of an (N,C,L) encoder output
+    (rnnt/model.py:27-28): shape (B,T,H), t-stride 1, h-stride T, same values."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     k = 1.0 / (H ** 0.5)
     enc = torch.randn(B, T, H, generator=g)
+    if permuted_enc:
+        enc = enc.permute(0, 2, 1).contiguous().to(device).permute(0, 2, 1)  # (N,C,L) storage, (N,L,C) view
     pred = torch.randn(B, U + 1, H, generator=g)
     W = (torch.rand(V, H, generator=g) * 2 - 1) * k
     bias = (torch.rand(V, generator=g) * 2 - 1) * k
     targets = torch.randint(0, V - 1, (B, U), generator=g, dtype=torch.int32)
     ll = torch.full((B,), T, dtype=torch.int32)
     tl = torch.full((B,), U, dtype=torch.int32)
-    return [x.to(device) for x in (enc, pred, W, bias, targets, ll, tl)]
+    return [x.to(device) for x in (enc, pred, W, bias, targets, ll, tl)]  # .to() keeps the permuted view's strides
 
 
 def cpu_baseline(T, U, H, V, budget_s=40.0):
-    """CPU port of the same path on this box's host cores: the reference's own torch-CPU op
-    sequence for the joint (oracle/torch_check.joint_torch == rnnt/joint.py:32-39) with torch
-    autograd, and the C restatement of the loss (oracle/rnnt_oracle.c, fp32, OpenMP over
-    utterances) standing in for torchaudio, which is absent from the image."""
+    """CPU port of the same path on this box's host cores, the two legs timed separately:
+    joint — the reference's own torch-CPU op sequence (oracle/torch_check.joint_torch == rnnt/joint.py:32-39)
+    forward + torch autograd backward, all torch threads; loss — the C restatement standing in for torchaudio
+    (absent from the image): rnnt_oracle_loss_par_f32, fp32, OpenMP over the (b,t,u) rows of the whole sample
+    for the log-softmax and gradient loops (every core busy), one utterance per thread for the small
+    alpha/beta recurrences."""
     from oracle import cpu_oracle
     from oracle.torch_check import joint_torch
     cpu_oracle.build()
@@ -75,23 +82,30 @@ def cpu_baseline(T, U, H, V, budget_s=40.0):
         W.requires_grad_(True); bias.requires_grad_(True)
         t0 = time.perf_counter()
         logits = joint_torch(enc, pred, W, bias)
-        costs, grad = cpu_oracle.rnnt_loss(logits.detach().numpy(), targets.numpy(), ll.numpy(),
-                                           tl.numpy(), dtype=np.float32)
+        t1 = time.perf_counter()
+        costs, grad = cpu_oracle.rnnt_loss_par_f32(logits.detach().numpy(), targets.numpy(), ll.numpy(), tl.numpy())
+        t2 = time.perf_counter()
         logits.backward(torch.from_numpy(grad) / B)
-        return time.perf_counter() - t0
+        t3 = time.perf_counter()
+        return t3 - t0, (t1 - t0) + (t3 - t2), t2 - t1
 
     one(1, max(8, T // 50))  # warm-up (thread pools, allocator)
-    t_probe = one(1, max(8, T // 10))
+    t_probe = one(1, max(8, T // 10))[0]
     est_full = t_probe * 10.0  # one utterance at full T
     # BASELINE.md §3 protocol: 1 warm-up, median of 3 runs; the three together are the ~10-30 s of
     # CPU work (the probe over-estimates: thread pools warm up), so each run gets a third
     B = int(max(1, min(8, round(budget_s / 3.0 / max(est_full, 1e-3)))))
     runs = sorted(one(B, T) for _ in range(3))
-    dt = runs[1]
+    dt, joint_s, loss_s = runs[1]
+    omp = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": B * T * U / dt, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, median of 3 runs ({runs[0]:.2f}/{runs[1]:.2f}/{runs[2]:.2f} s) "
-                      f"of joint (torch CPU, {threads} threads) + loss (C oracle, OpenMP over the {B} utterances) fwd+bwd",
-            "runs_s": runs, "os_cpu_count": os.cpu_count()}
+            "joint_s": joint_s, "loss_s": loss_s,
+            "joint_cells_per_s": B * T * U / joint_s, "loss_cells_per_s": B * T * U / loss_s,
+            "threads_busy": {"joint": threads, "loss_rows": omp, "loss_lattice": min(B, omp)},
+            "sample": f"B={B},T={T},U={U},H={H},V={V} fp32, median of 3 runs ({runs[0][0]:.2f}/{runs[1][0]:.2f}/{runs[2][0]:.2f} s): "
+                      f"joint fwd+bwd (torch CPU, {threads} threads) {joint_s:.2f} s + loss fwd+grad (C port, OpenMP over "
+                      f"all {B * T * (U + 1)} (b,t,u) rows on {omp} threads; alpha/beta one utterance per thread) {loss_s:.2f} s",
+            "runs_s": [r[0] for r in runs], "os_cpu_count": os.cpu_count()}
 
 
 def parity_twin(H, V, device, dtype="fp32"):
@@ -105,7 +119,7 @@ def parity_twin(H, V, device, dtype="fp32"):
                                               t["logit_lens"], t["target_lens"], V - 1, 0.5,
                                               dtype=dtype)
     torch.cuda.synchronize()
-    ref = oracle_fused_bf16(d) if dtype == "bf16" else oracle_fused(d)
+    ref = oracle_fused_bf16(d) if dtype == "bf16" else oracle_fused(d)  # bf16x3: the plain fp64 oracle, fp32's bar
     loss = float(outs[0].double().mean())
     gerr = max(float(np.abs(o.cpu().numpy() - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30))
                for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")))
@@ -183,11 +197,16 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)   # >= 5 warm-ups, median of >= 20
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16 = BASELINE config 3's arithmetic (bf16 GEMM operands, fp32 accumulate)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="fp32 = exact fp32 MFMA; bf16x3 = fp32-ACCURATE results from six bf16 MFMA products of "
+                         "3-way split operands (RNNT_DTYPE_F32_BF16X3, same 1e-4 parity bar); "
+                         "bf16 = BASELINE config 3's arithmetic (bf16 GEMM operands, fp32 accumulate)")
+    ap.add_argument("--permuted-enc", action="store_true",
+                    help="hand `enc` over as the reference does: the permute(0,2,1) view of an (N,C,L) tensor "
+                         "(rnnt/model.py:27-28); the engine's tiled transpose is then part of every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
@@ -229,7 +248,7 @@ def main():
     if B % world != 0:
         raise SystemExit(f"global batch {B} not divisible by {world} ranks")
     Bl = B // world  # contiguous batch shard per rank (strong scaling: global batch fixed)
-    enc, pred, W, bias, targets, ll, tl = synth(Bl, T, U, H, V, 1234 + rank, device)
+    enc, pred, W, bias, targets, ll, tl = synth(Bl, T, U, H, V, 1234 + rank, device, permuted_enc=args.permuted_enc)
     if dist_on:  # parameters are replicated: rank 0's W/bias everywhere
         dist.broadcast(W, 0); dist.broadcast(bias, 0)
     scale = 1.0 / B
@@ -260,17 +279,25 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    # The contract's number: EXACTLY K steps between two (barrier + synchronize) brackets, wall clock, max over
+    # ranks.  Beside it, SURVEY §8d's protocol: a HIP-event pair around every one of those K steps on the launch
+    # stream (torch's current stream IS the stream the engine enqueues on), median reported.
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for e0, e1 in evs:
+        e0.record()
         step()
+        e1.record()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    med_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    tmax = torch.tensor([dt, med_ms], dtype=torch.float64, device=device)
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, med_ms = float(tmax[0].item()), float(tmax[1].item())
     loss = float(flat[V * H + V].item())
 
     # ---- per-stage timing with HIP events on the launch stream (torch's current stream IS the
@@ -305,9 +332,21 @@ def main():
         "value": cells_global * args.steps / dt,
         "unit": "cells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        # SURVEY §8d protocol beside the contract's wall-clock mean: HIP-event pair per step, median (max over ranks)
+        "ms_per_step_median": med_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
+        "value_at_median": cells_global / (med_ms * 1e-3),
+        "timing": f"value/ms_per_step: wall clock over {args.steps} steps between barrier+synchronize brackets, max over "
+                  f"ranks; ms_per_step_median: hipEventElapsedTime per step, median of {args.steps}",
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} {args.dtype} joint+loss fwd+bwd",
+        # dtype = the type the results are accurate to (bf16x3 meets the fp32 route's 1e-4 parity bar: tests/,
+        # `parity` below); arith = how the products are formed
+        "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+        "arith": {"fp32": "v_mfma_f32_32x32x2_f32 (exact fp32 products)",
+                  "bf16x3": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (operands split hi+mid+lo), fp32 accumulate",
+                  "bf16": "v_mfma_f32_32x32x16_bf16 on bf16-rounded operands, fp32 accumulate, fp16 logits"}[args.dtype],
+        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} {args.dtype} joint+loss fwd+bwd" +
+                               (", enc = permuted (N,C,L) view" if args.permuted_enc else ""),
+                   "enc_layout": "permute(0,2,1) view of (N,C,L), as rnnt/model.py:27-28" if args.permuted_enc else "contiguous (B,T,H)",
                    "global_batch": B, "per_gpu_batch": Bl, "parallelism": f"dp{world}",
                    "cells_BTU1": B * T * (U + 1)},
         "loss": loss,
@@ -324,10 +363,13 @@ def main():
         gemms = {k: stage_ms[k] for k in ("joint_fwd_gemm", "dhidden_gemm", "dw_gemm")}
         dom = max(gemms, key=gemms.get)
         ach = 2.0 * H * V * cells1 / (gemms[dom] * 1e-3) / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype != "bf16x3" else PEAK_BF16_MFMA_TFLOPS / 6.0
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach,
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "peak": peak, "unit": "TFLOP/s",
+                           "frac": ach / peak, "traffic": None,
                            "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
+        if args.dtype == "bf16x3":
+            out["roofline"]["peak_note"] = "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 products per fp32 product (fp32-equivalent flops)"
         if args.dtype == "bf16":
             # 16x the matrix rate: every kernel of this route is HBM-bound.  Algorithmic bytes per
             # cell (rnnt_amd/csrc/bf16.hip header; logits stored fp16): fwd 2H+2V, dHidden 2V+2V+2H, dW 2V+2H
@@ -340,13 +382,16 @@ def main():
         # HBM traffic of that kernel: not measurable from inside the process; taken from the PMC
         # profile committed for this config (profiles/r01_traffic.json), else null
         try:
-            key = args.config if args.dtype == "fp32" else args.config + "_bf16"
+            key = args.config if args.dtype == "fp32" else args.config + "_" + args.dtype
             tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))[-1]
             tr = json.load(open(os.path.join(ROOT, "profiles", tfile)))[key][dom]
             if world == 1:
                 # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane
                 # streams (every load of these kernels is 16 B/lane) -> doubled; WRITE_SIZE is exact
                 out["roofline"]["traffic"] = 2 * tr["fetch_raw"] + tr["write"]
+                # REPLAYED from the committed PMC profile of this config, not measured in this run
+                out["roofline"]["traffic_source"] = {"file": "profiles/" + tfile, "replayed": True,
+                                                     "commit": tr.get("commit") or json.load(open(os.path.join(ROOT, "profiles", tfile))).get("commit")}
                 out["roofline"]["traffic_note"] = ("bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 PMC, separate "
                                                    "passes, KB x 1024; gfx950 half-count correction for 16 B/lane loads), "
                                                    "profiles/%s; algorithmic HBM bytes %.3g" % (tfile, tr["algorithmic"]))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RNNT_ENGINE_VERSION 2
+#define RNNT_ENGINE_VERSION 3
 
 #define RNNT_DTYPE_F32 0 /* fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out */
 /* BASELINE config 3 ("bf16"): pointers stay fp32 at this boundary (inputs, parameters, costs,
@@ -47,6 +47,13 @@ extern "C" {
  * entry only (rnnt_engine_joint_loss_fwd_bwd, rnnt_engine_run_stage, the workspace queries);
  * needs H % 128 == 0, V % 128 == 0. */
 #define RNNT_DTYPE_BF16 1
+/* fp32-ACCURATE arithmetic on the bf16 matrix pipes ("bf16x3"): same boundary, same 1e-4 parity bar as
+ * RNNT_DTYPE_F32 — every operand of the three GEMMs is split once into three bf16 pieces (hi + mid + lo
+ * = the fp32 value to 2^-25) and each product is the sum of six bf16 MFMA products with fp32 accumulation
+ * (rnnt_amd/csrc/x3.hip); logits stay fp32, log-softmax / lattice / reductions are the fp32 route's.
+ * Measured error against fp64 is below the fp32 MFMA route's (tools/bf16x3_accuracy.py, tests).  Fused
+ * entry only; needs H % 128 == 0, V % 128 == 0 (the Python host side zero-pads other shapes). */
+#define RNNT_DTYPE_F32_BF16X3 2
 
 #define RNNT_OK 0
 #define RNNT_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim, bad blank ...        */
@@ -70,6 +77,11 @@ void rnnt_engine_set_debug(void *buf);
 #define RNNT_VARIANT_SEPARATE_HIDDEN 64     /* hidden by its own pass instead of the forward prologue       */
 #define RNNT_VARIANT_FWD_LDS_RING 128       /* forward main loop: W through an LDS-DMA ring                 */
 #define RNNT_VARIANT_FWD_ONE_WG_PER_TILE 256 /* forward: one workgroup per tile instead of persistent ones   */
+/* RNNT_DTYPE_F32_BF16X3 only: run one stage on the fp32 route's kernel instead of the bf16x3 one (same data
+ * layout downstream, plain splitting kernels in between) — how each bf16x3 kernel is checked in isolation.
+ * NOT bit-identical to the default bf16x3 kernels (different summation), same tolerance. */
+#define RNNT_VARIANT_X3_FP32_FWD 4096       /* forward GEMM + hidden by the fp32 kernel, then k_x3_make_hidden */
+#define RNNT_VARIANT_X3_FP32_DH 8192        /* dHidden + G by the fp32 kernels, then k_x3_split_g (needs _FWD too) */
 
 /* Diagnostic queries (0/1: predicted resident forward-kernel workgroups per CU). */
 int rnnt_engine_debug_query(int what);
@@ -288,6 +300,7 @@ typedef struct rnnt_engine_ws_layout {
     size_t logits, hidden, denom_s, lpb_s, lpe_s, alpha_s, beta_s, coef, wpack, enc_copy;
     size_t slab_enc, slab_pred, slab_w, slab_b, counters, total, rows_pad;
     int n_ublk, n_ttile, n_split, D;
+    size_t g_lo, aux; /* RNNT_DTYPE_F32_BF16X3: lo plane of G; fp32 hidden + W pack of the _X3_FP32_ variants */
 } rnnt_engine_ws_layout;
 
 int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,

@@ -85,6 +85,24 @@ def rnnt_loss(logits, targets, logit_lens, target_lens, blank=-1, clamp=-1.0,
     return costs, grad
 
 
+def rnnt_loss_par_f32(logits, targets, logit_lens, target_lens, blank=-1, want_grad=True):
+    """bench.py's cpu_baseline only: rnnt_loss in fp32 with the O(T*U1*V) loops spread over all (b,t,u)
+    rows by OpenMP (rnnt_oracle_loss_par_f32).  Same call as reference rnnt/model.py:35-41."""
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    B, T, U1, V = logits.shape
+    targets = np.ascontiguousarray(targets, dtype=np.int32).reshape(B, U1 - 1)
+    logit_lens = np.ascontiguousarray(logit_lens, dtype=np.int32)
+    target_lens = np.ascontiguousarray(target_lens, dtype=np.int32)
+    costs = np.empty(B, dtype=np.float32)
+    grad = np.empty_like(logits) if want_grad else None
+    fn = lib().rnnt_oracle_loss_par_f32
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
+    fn.restype = None
+    fn(_ptr(logits), _ptr(targets), _ptr(logit_lens), _ptr(target_lens), B, T, U1, V, int(blank),
+       _ptr(costs), _ptr(grad))
+    return costs, grad
+
+
 def joint_bwd(enc, pred, W, G, dtype=np.float64):
     """Autograd of reference rnnt/joint.py:32-39 for upstream gradient G[B,T,U1,V]."""
     sfx, _ = _sfx(dtype)

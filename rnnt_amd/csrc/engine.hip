@@ -49,12 +49,13 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
 {
-    if (dtype != RNNT_DTYPE_F32 && dtype != RNNT_DTYPE_BF16)
-        return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (RNNT_DTYPE_F32 / RNNT_DTYPE_BF16)", dtype);
-    if (dtype == RNNT_DTYPE_BF16 && !need_h)
-        return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 only applies to the fused joint+loss entry");
-    if (dtype == RNNT_DTYPE_BF16 && (H <= 0 || H % 128 != 0 || V <= 0 || V % 128 != 0))
-        return fail(RNNT_ERR_UNSUPPORTED, "RNNT_DTYPE_BF16 needs H %% 128 == 0 and V %% 128 == 0 (H=%d V=%d)", H, V);
+    if (dtype != RNNT_DTYPE_F32 && dtype != RNNT_DTYPE_BF16 && dtype != RNNT_DTYPE_F32_BF16X3)
+        return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (RNNT_DTYPE_F32 / RNNT_DTYPE_BF16 / RNNT_DTYPE_F32_BF16X3)", dtype);
+    const char *dname = dtype == RNNT_DTYPE_BF16 ? "RNNT_DTYPE_BF16" : "RNNT_DTYPE_F32_BF16X3";
+    if (dtype != RNNT_DTYPE_F32 && !need_h)
+        return fail(RNNT_ERR_UNSUPPORTED, "%s only applies to the fused joint+loss entry", dname);
+    if (dtype != RNNT_DTYPE_F32 && (H <= 0 || H % 128 != 0 || V <= 0 || V % 128 != 0))
+        return fail(RNNT_ERR_UNSUPPORTED, "%s needs H %% 128 == 0 and V %% 128 == 0 (H=%d V=%d)", dname, H, V);
     if (B <= 0 || T <= 0 || U1 <= 0 || V <= 0 || (need_h && H <= 0))
         return fail(RNNT_ERR_INVALID_ARG, "non-positive dimension B=%d T=%d U1=%d H=%d V=%d", B, T, U1, H, V);
     if (V % 4 != 0) return fail(RNNT_ERR_UNSUPPORTED, "V=%d must be a multiple of 4 (pad on the host side)", V);
@@ -66,7 +67,7 @@ int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
 
 int dw_splits(int B, int T, int H, int V, int dtype)
 {
-    const long tiles = dtype == RNNT_DTYPE_BF16 ? (long)((V + 255) / 256) * ((H + 255) / 256) : dw_tiles(H, V);
+    const long tiles = dtype != RNNT_DTYPE_F32 ? (long)((V + 255) / 256) * ((H + 255) / 256) : dw_tiles(H, V);
     long s = 256 / tiles;
     if (s < 1) s = 1;
     if (s > (long)B * T) s = (long)B * T;
@@ -80,20 +81,28 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
 {
     const size_t D = (size_t)T + U1 - 1;
     const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
+    const bool bf = dtype == RNNT_DTYPE_BF16, x3 = dtype == RNNT_DTYPE_F32_BF16X3;
     // G / hidden rows are padded with >= 1 zero row up to a multiple of 16 (dW chunk size)
-    // (bf16 route: multiple of 32 = one dW stage)
-    const size_t rows_pad = dtype == RNNT_DTYPE_BF16 ? (cells + 1 + 31) / 32 * 32 : (cells + 1 + 15) / 16 * 16;
+    // (bf16 / bf16x3 routes: multiple of 32 = one granule of their live-row table)
+    const size_t rows_pad = (bf || x3) ? (cells + 1 + 31) / 32 * 32 : (cells + 1 + 15) / 16 * 16;
     L->rows_pad = rows_pad;
     L->D = (int)D;
-    // dEnc slabs: one per u block; the fp32 route's fused dHidden kernel may use 8-wide blocks
-    L->n_ublk = dtype == RNNT_DTYPE_BF16 ? (U1 + 15) / 16 : (U1 + dhidden_gen_bu(T, U1) - 1) / dhidden_gen_bu(T, U1);
+    // dEnc slabs: one per u block; the fp32 route's fused dHidden kernel may use 8-wide blocks (the bf16x3
+    // route can run its dHidden stage on that kernel: RNNT_VARIANT_X3_FP32_DH)
+    L->n_ublk = bf ? (U1 + 15) / 16 : x3 ? (U1 + 7) / 8 : (U1 + dhidden_gen_bu(T, U1) - 1) / dhidden_gen_bu(T, U1);
     L->n_ttile = (T + 3) / 4;  // dPred slabs: at most one per 4 t rows (the persistent kernel's 16-wide items)
     L->n_split = dw_splits(B, T, H, V, dtype);
+    L->g_lo = 0; L->aux = 0;
     size_t o = 0;
-    if (dtype == RNNT_DTYPE_BF16) {
+    if (bf) {
         const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
         L->logits = o;   o += align_up(ra * V * 2);  // fp16
         L->hidden = o;   o += align_up(ra * H * 2);
+    } else if (x3) {
+        const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
+        L->logits = o;   o += align_up(ra * V * 4);      // fp32 logits; G hi | mid planes in place
+        L->hidden = o;   o += align_up(3 * ra * H * 2);  // three bf16 planes
+        L->g_lo = o;     o += align_up(ra * V * 2);      // lo plane of G
     } else {
         L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
         L->hidden = o;   o += align_up((rows_pad + 16) * H * 4);
@@ -105,16 +114,20 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->beta_s = o;   o += align_up(skew * 8);
     L->coef = o;     o += align_up(cells * 16);
     L->wpack = o;
-    if (dtype == RNNT_DTYPE_BF16) o += align_up(bf16_wpack_fwd_bytes(H, V)) + align_up(bf16_wpack_dh_bytes(H, V));
+    if (bf) o += align_up(bf16_wpack_fwd_bytes(H, V)) + align_up(bf16_wpack_dh_bytes(H, V));
+    else if (x3) o += align_up(x3_wpack_fwd_bytes(H, V)) + align_up(x3_wpack_dh_bytes(H, V));
     else o += align_up(wpack_floats(H, V) * 4);
     L->enc_copy = o; o += align_up((size_t)B * T * H * 4);
     L->slab_enc = o; o += align_up((size_t)L->n_ublk * B * T * H * 4);
     L->slab_pred = o; o += align_up((size_t)L->n_ttile * B * U1 * H * 4);
     L->slab_w = o;   o += align_up((size_t)L->n_split * V * H * 4);
     L->slab_b = o;   o += align_up((size_t)L->n_split * V * 4);
-    {   // + the dW live-row table (bf16 route) / live-granule list (fp32 route), whichever is larger
-        const size_t tab = (2 * (size_t)B + 2) * 8, lst = dtype == RNNT_DTYPE_BF16 ? 0 : dw_list_bytes(B, T, U1, 16);
+    {   // + the dW live-row table (bf16 routes) / live-granule list (fp32 route), whichever is larger
+        const size_t tab = (2 * (size_t)B + 2) * 8, lst = (bf || x3) ? 0 : dw_list_bytes(B, T, U1, 16);
         L->counters = o; o += 1024 + align_up(tab > lst ? tab : lst);
+    }
+    if (x3) {  // fp32 hidden + fp32 W pack of the stages that can run on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*)
+        L->aux = o; o += align_up((rows_pad + 16) * H * 4) + align_up(wpack_floats(H, V) * 4);
     }
     L->total = o;
 }
@@ -225,7 +238,8 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         ((uintptr_t)workspace & 255))
         return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
     const int xflags = g_flags | (variant & (RNNT_VARIANT_SEPARATE_G | RNNT_VARIANT_SEPARATE_HIDDEN |
-                                             RNNT_VARIANT_FWD_LDS_RING | RNNT_VARIANT_FWD_ONE_WG_PER_TILE));
+                                             RNNT_VARIANT_FWD_LDS_RING | RNNT_VARIANT_FWD_ONE_WG_PER_TILE |
+                                             RNNT_VARIANT_X3_FP32_FWD | RNNT_VARIANT_X3_FP32_DH));
     rnnt_engine_ws_layout L;
     layout(B, T, U1, H, V, dtype, &L);
     if (ws_bytes < L.total)
@@ -255,6 +269,79 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
     g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = xflags & ~16; g.debug = g_debug; g.pred_split_col = 0;
     g.gen_bu = dtype == RNNT_DTYPE_BF16 ? 16 : dhidden_gen_bu(T, U1);  // u width of the dHidden tiles
+    if (dtype == RNNT_DTYPE_F32_BF16X3) {
+        // fp32-accurate route on the bf16 matrix pipes (x3.hip).  Stage by stage the fp32 route's own kernel can
+        // stand in (RNNT_VARIANT_X3_FP32_FWD / _DH): same data, one stage swapped — how each x3 kernel is checked.
+        X3Args h;
+        h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;
+        h.W = (const float *)W; h.bias = (const float *)bias;
+        h.rows_pad = (long)L.rows_pad; h.rows_alloc = bf16_rows_alloc(L.rows_pad);
+        h.hidden = (unsigned short *)(ws + L.hidden); h.plane_stride = h.rows_alloc * (long)H;
+        h.wpack_fwd = ws + L.wpack; h.wpack_dh = ws + L.wpack + align_up(x3_wpack_fwd_bytes(H, V));
+        h.logits = logits; h.g_lo = (unsigned short *)(ws + L.g_lo); h.coef = coef;
+        h.targets = targets; h.logit_lens = logit_lens; h.target_lens = target_lens;
+        h.denom_s = denom_s; h.lpb_s = lpb_s; h.lpe_s = lpe_s; h.D = L.D;
+        h.slab_enc = g.slab_enc; h.slab_pred = g.slab_pred; h.slab_w = g.slab_w; h.slab_b = g.slab_b;
+        h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
+        h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags;
+        h.dw_tab = (long *)(ws + L.counters + 1024);
+        h.counter = (unsigned *)(ws + L.counters + 512); h.n_cu = device_cus();
+        const bool f32_dh = (xflags & RNNT_VARIANT_X3_FP32_DH) != 0 || !x3_dhidden_ok(U1, H, V);
+        const bool f32_fwd = (xflags & RNNT_VARIANT_X3_FP32_FWD) != 0 || !x3_fwd_ok(U1, H, V) || f32_dh;  // fp32 dHidden reads fp32 hidden
+        float *hid32 = (float *)(ws + L.aux);
+        float *wpack32 = (float *)(ws + L.aux + align_up((L.rows_pad + 16) * (size_t)H * 4));
+        g.hidden = hid32;
+        const bool fuse_g32 = dhidden_gen_ok(H, V, U1);
+        if (f32_dh) {
+            if (fuse_g32) { g.flags |= 16; g.pred_split_col = 512 * dhidden_gen_groups(H); }
+        } else {
+            g.gen_bu = 16; g.pred_split_col = H;  // x3 tiles: 8 t x 16 u, every dPred slab 8 t rows high
+        }
+        if (stages & ST_PROD) {
+            launch_x3_zero_padding(h, st);
+            launch_x3_pack_w(h, st);
+            if (f32_fwd) {
+                const size_t cells = (size_t)B * T * U1;
+                launch_fill32(hid32 + cells * H, 0u, (L.rows_pad + 16 - cells) * H * 4, st);
+                launch_zero_dead_hidden(hid32, logit_lens, target_lens, B, T, U1, H, st);
+                launch_pack_w_fwd((const float *)W, wpack32, H, V, st);
+            }
+        }
+        if (stages & ST_FWD) {
+            if (f32_fwd) {
+                JointFwdArgs f;
+                f.enc = encp; f.enc_sb = esb; f.enc_st = est; f.pred = (const float *)pred;
+                f.wpack = wpack32; f.hidden = hid32; f.bias = (const float *)bias; f.targets = targets;
+                f.logit_lens = logit_lens; f.target_lens = target_lens; f.logits = logits;
+                f.denom_s = denom_s; f.lpb_s = lpb_s; f.lpe_s = lpe_s;
+                f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = 0; f.debug = nullptr;
+                f.make_hidden = 1; f.counter = h.counter; f.n_cu = h.n_cu;
+                launch_joint_fwd(f, st);
+                launch_x3_make_hidden(h, st);  // the planes the backward reads
+            } else {
+                launch_joint_fwd_x3(h, st);
+            }
+        }
+        if (stages & ST_LATTICE)
+            launch_lattice(lpb_s, lpe_s, alpha_s, beta_s, logit_lens, target_lens, costs, B, U1, L.D,
+                           (unsigned *)(ws + L.counters + 768), st);
+        if (stages & ST_COEF)
+            launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
+                        B, T, U1, L.D, grad_scale, st);
+        if (stages & ST_DH) {
+            if (f32_dh) {
+                if (!fuse_g32) launch_make_g(g, st);
+                launch_dhidden(g, st);     // leaves fp32 G in place of the logits
+                launch_x3_split_g(h, st);  // -> hi | mid in place, lo beside
+            } else {
+                launch_dhidden_x3(h, st);
+            }
+        }
+        if (stages & ST_DH_RED) launch_dhidden_reduce(g, st);
+        if (stages & ST_DW) launch_dw_x3(h, st);
+        if (stages & ST_DW_RED) launch_dw_reduce(g, st);
+        return launch_status("rnnt_engine fused pipeline (bf16x3)");
+    }
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;
         h.enc = encp; h.enc_sb = esb; h.enc_st = est; h.pred = (const float *)pred;

@@ -126,9 +126,42 @@ void launch_zero_dead_hidden(float *hidden, const int32_t *logit_lens, const int
     hipLaunchKernelGGL(k_zero_dead_hidden, dim3(T, B), dim3(256), 0, st, hidden, logit_lens, target_lens, B, T, U1, H);
 }
 
+// The view the reference really hands over: `encoder(mel).permute(0, 2, 1)` (rnnt/model.py:27-28) —
+// shape (B,T,H) over an (N,C,L) tensor, so consecutive t are contiguous (t-stride 1) and consecutive h
+// are T floats apart.  The element-per-thread copy above reads it with 64 lanes in 64 different rows
+// (the guide's worst access shape, ~17x slower than coalesced).  Here a 64 t x 64 h tile goes through
+// LDS: global reads run along t (256 contiguous bytes per wave-instruction), global writes along h;
+// the 65-float row pitch keeps both LDS phases conflict-free.  grid (ceil(T/64), ceil(H/64), B).
+__global__ __launch_bounds__(256) void k_transpose_enc(const float *__restrict__ enc, long sb, long sh,
+                                                       float *__restrict__ dst, int T, int H)
+{
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+    const long b = blockIdx.z;
+    const float *src = enc + b * sb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int h = h0 + ty + 4 * i, t = t0 + tx;
+        if (h < H && t < T) tile[ty + 4 * i][tx] = src[(long)h * sh + t];
+    }
+    __syncthreads();
+    float *out = dst + b * T * H;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int t = t0 + ty + 4 * i, h = h0 + tx;
+        if (t < T && h < H) out[(long)t * H + h] = tile[tx][ty + 4 * i];
+    }
+}
+
 void launch_copy_enc(const float *enc, long sb, long st_, long sh, float *dst, int B, int T, int H,
                      hipStream_t st)
 {
+    if (st_ == 1 && sh != 1) {  // the permuted (N,C,L) view: tiled transpose
+        hipLaunchKernelGGL(k_transpose_enc, dim3((T + 63) / 64, (H + 63) / 64, B), dim3(256), 0, st, enc, sb, sh,
+                           dst, T, H);
+        return;
+    }
     const long n = (long)B * T * H;
     hipLaunchKernelGGL(k_copy_enc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, enc, sb,
                        st_, sh, dst, B, T, H);

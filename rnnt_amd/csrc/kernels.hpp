@@ -120,6 +120,43 @@ void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st);
 void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st);
 void launch_dw_bf16(const Bf16Args &a, hipStream_t st);
 
+// ---- x3.hip (RNNT_DTYPE_F32_BF16X3 route: fp32-accurate products as six bf16 MFMA products of 3-way split operands)
+struct X3Args {
+    const float *enc; long enc_sb, enc_st;
+    const float *pred;
+    const float *W;      // [V,H] fp32 (split and re-packed in fragment order every call)
+    const float *bias;
+    unsigned short *hidden;  // bf16 planes [3][rows_alloc][H] of tanh(enc+pred): hi, mid, lo
+    long plane_stride;       // elements between two planes of `hidden` (= rows_alloc * H)
+    void *wpack_fwd, *wpack_dh;
+    float *logits;           // fp32 [rows_alloc,V]; G's hi | mid planes overwrite each 32-wide chunk in place
+    unsigned short *g_lo;    // bf16 [rows_alloc,V]: lo plane of G
+    const CellCoef *coef;
+    const int32_t *targets, *logit_lens, *target_lens;
+    float *denom_s, *lpb_s, *lpe_s;  // skewed [B,D,U1] softmax statistics (forward epilogue)
+    int D;
+    float *slab_enc, *slab_pred, *slab_w, *slab_b;
+    long rows_alloc;     // multiple of 128, >= rows_pad + 96; rows >= B*T*U1 are zero
+    long rows_pad;       // K extent of the dW GEMM (multiple of 32)
+    int B, T, U1, H, V, blank;
+    int n_ublk, n_split;
+    int flags;
+    long *dw_tab;        // 2B+2 longs: live-row table of k_dw_x3 (k_dw_table, 32-cell granules)
+    unsigned *counter;   // zeroable word: tile counter of the persistent forward
+    int n_cu;
+};
+bool x3_fwd_ok(int U1, int H, int V);      // the bf16x3 forward kernel covers this shape (else: the fp32 route's)
+bool x3_dhidden_ok(int U1, int H, int V);  // likewise k_dhidden_x3
+size_t x3_wpack_fwd_bytes(int H, int V);
+size_t x3_wpack_dh_bytes(int H, int V);
+void launch_x3_make_hidden(const X3Args &a, hipStream_t st);
+void launch_x3_split_g(const X3Args &a, hipStream_t st);
+void launch_x3_zero_padding(const X3Args &a, hipStream_t st);
+void launch_x3_pack_w(const X3Args &a, hipStream_t st);
+void launch_joint_fwd_x3(const X3Args &a, hipStream_t st);
+void launch_dhidden_x3(const X3Args &a, hipStream_t st);
+void launch_dw_x3(const X3Args &a, hipStream_t st);
+
 // ---- decode.hip
 void launch_scan_logits(const float *enc, long enc_st, const float *pred, const float *W, const float *bias,
                         float *logits, int K, int H, int V, hipStream_t st);

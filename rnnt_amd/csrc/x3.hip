@@ -1,0 +1,404 @@
+// x3.hip — the RNNT_DTYPE_F32_BF16X3 route: fp32-accurate arithmetic on the bf16 matrix pipes.
+//
+// Same path and same boundary as the fp32 route (reference rnnt/joint.py:32-39 + torchaudio rnnt_loss
+// called at rnnt/model.py:35-41 + their autograd; fp32 tensors in and out, 1e-4 parity bar), but the
+// three GEMMs run on v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_32x32x2_f32 (1/16 of its rate):
+// every fp32 operand x is split ONCE, where it is produced, into three bf16 pieces
+//       x = hi + mid + lo     hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)   (RNE each)
+// (8 + 8 + 8 significant bits: the sum is x to 2^-25 relative) and a product a.b is evaluated as the
+// six bf16 products  ah.bh + ah.bm + am.bh + am.bm + ah.bl + al.bh  accumulated in fp32 by the MFMA —
+// the terms dropped are <= 2^-24 |a.b|.  Measured against fp64 (tools/bf16x3_accuracy.py): rms error
+// 4.4e-8 of the logit scale, against 1.2e-7 for the fp32 MFMA's 512-long fp32 accumulation chain.
+// Logits, log-softmax, the lattice, the gradient coefficients and every reduction are the fp32 / fp64
+// code of the fp32 route (lattice.hip); only the operands of the matrix products are split.
+//
+// Data (workspace):
+//   hidden  3 planes bf16 [3][rows_alloc][H]      written by the forward tile's prologue
+//   logits  fp32 [rows_alloc][V]                  forward -> k_dhidden_x3
+//   G       hi and mid planes IN PLACE of the logits: the 128 bytes of every 32-wide chunk of a logits
+//           row become [32 x hi | 32 x mid]; lo plane bf16 [rows_alloc][V] beside it (workspace `g_lo`)
+//   W       re-packed per call into MFMA-fragment order, 3 planes (forward: wpack_fwd, dHidden: wpack_dh)
+//
+// MFMA operand maps (cdna_hip_programming.md §3): lane l = (r = l&31, h = l>>5) holds A[row r][k = 8h+j]
+// and B[k = 8h+j][col r], j = 0..7; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// Every kernel here is 4 waves (one per SIMD) with 256 accumulator registers per wave, hand-pipelined
+// around long MFMA streams (96 MFMAs = 3072 matrix-pipe cycles per 16-deep k-step), like the fp32 route's.
+#include "kernels.hpp"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((address_space(3))) void *lds_vptr;
+
+__device__ __forceinline__ unsigned x3_pack(float lo, float hi)
+{
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32: RNE
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float x3_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float x3_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// two fp32 values -> their (hi, mid, lo) bf16 pieces, packed pairwise (element 0 in the low half)
+struct X3Pieces { unsigned h, m, l; };
+__device__ __forceinline__ X3Pieces x3_split2(float a, float b)
+{
+    X3Pieces p;
+    p.h = x3_pack(a, b);
+    const float ra = a - x3_lo(p.h), rb = b - x3_hi(p.h);  // exact: the residual has <= 16 significant bits
+    p.m = x3_pack(ra, rb);
+    p.l = x3_pack(ra - x3_lo(p.m), rb - x3_hi(p.m));
+    return p;
+}
+// four consecutive fp32 values -> (2 packed dwords per plane) at dword positions d, d+1 of the plane vectors
+#define X3_SPLIT4(x4, ph, pm, pl, d)                                  \
+    do {                                                              \
+        const X3Pieces p0_ = x3_split2((x4)[0], (x4)[1]);             \
+        const X3Pieces p1_ = x3_split2((x4)[2], (x4)[3]);             \
+        (ph)[d] = p0_.h; (pm)[d] = p0_.m; (pl)[d] = p0_.l;            \
+        (ph)[(d) + 1] = p1_.h; (pm)[(d) + 1] = p1_.m; (pl)[(d) + 1] = p1_.l; \
+    } while (0)
+__device__ __forceinline__ f32x16 x3_mfma(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void x3_lds_barrier()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Plain producers.  k_x3_make_hidden / k_x3_split_g are the one-thread-per-piece forms of what the
+// forward prologue and k_dhidden_x3 do in their tiles: they serve the unfused variants
+// (RNNT_VARIANT_X3_*), which exist so that every fused kernel can be checked against the same
+// pipeline with one stage swapped, and as the plain statement of the data layout.
+// ---------------------------------------------------------------------------------------
+// hidden planes of every cell (also dead ones: the backward multiplies them by exact zeros, they only
+// have to be finite).  One thread = 8 columns of one row.
+__global__ __launch_bounds__(256) void k_x3_make_hidden(X3Args a)
+{
+    const int H8 = a.H / 8;
+    const long cells = (long)a.B * a.T * a.U1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cells * H8) return;
+    const long c = idx / H8;
+    const int h = (int)(idx - c * H8) * 8;
+    const int u = (int)(c % a.U1);
+    const long bt = c / a.U1;
+    const int t = (int)(bt % a.T), b = (int)(bt / a.T);
+    const float *ep = a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + h;
+    const float *pp = a.pred + ((long)b * a.U1 + u) * a.H + h;
+    const f32x4 t0 = fast_tanh_sum4(*(const f32x4 *)ep, *(const f32x4 *)pp);
+    const f32x4 t1 = fast_tanh_sum4(*(const f32x4 *)(ep + 4), *(const f32x4 *)(pp + 4));
+    u32x4 ph, pm, pl;
+    X3_SPLIT4(t0, ph, pm, pl, 0);
+    X3_SPLIT4(t1, ph, pm, pl, 2);
+    u32x4 *o = (u32x4 *)(a.hidden + c * a.H + h);
+    const long ps = a.plane_stride / 8;  // u32x4 units
+    o[0] = ph; o[ps] = pm; o[2 * ps] = pl;
+}
+
+// fp32 G (what the fp32 route's k_dhidden_gen / k_make_g leave in place of the logits) -> the three
+// planes: hi | mid over the same 128 bytes of every 32-wide chunk, lo beside.  One thread = one chunk
+// of one row (it reads the whole 128 bytes before it overwrites them).
+__global__ __launch_bounds__(256) void k_x3_split_g(X3Args a, long rows)
+{
+    const int VC = a.V / 32;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * VC) return;
+    const long r = idx / VC;
+    const int c = (int)(idx - r * VC);
+    f32x4 *p = (f32x4 *)(a.logits + r * a.V + 32 * c);
+    f32x4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = p[i];
+    u32x4 ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) X3_SPLIT4(x[i], ph[i >> 1], pm[i >> 1], pl[i >> 1], 2 * (i & 1));
+    u32x4 *o = (u32x4 *)p;
+    u32x4 *ol = (u32x4 *)(a.g_lo + r * a.V + 32 * c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = ph[i]; o[4 + i] = pm[i]; ol[i] = pl[i]; }
+}
+
+void launch_x3_make_hidden(const X3Args &a, hipStream_t st)
+{
+    const long n = (long)a.B * a.T * a.U1 * (a.H / 8);
+    hipLaunchKernelGGL(k_x3_make_hidden, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_x3_split_g(const X3Args &a, hipStream_t st)
+{
+    const long rows = (long)a.B * a.T * a.U1;
+    const long n = rows * (a.V / 32);
+    hipLaunchKernelGGL(k_x3_split_g, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, rows);
+}
+// zero rows past the last cell, all planes (the dW ring walks up to 96 of them; dead rows of dHidden tiles)
+void launch_x3_zero_padding(const X3Args &a, hipStream_t st)
+{
+    const long cells = (long)a.B * a.T * a.U1;
+    const size_t pad = (size_t)(a.rows_alloc - cells);
+    for (int p = 0; p < 3; ++p) launch_fill32(a.hidden + p * a.plane_stride + cells * a.H, 0u, pad * a.H * 2, st);
+    launch_fill32(a.logits + cells * a.V, 0u, pad * a.V * 4, st);
+    launch_fill32(a.g_lo + cells * a.V, 0u, pad * a.V * 2, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_dw_x3: dW[v,h] = sum_c G[c,v] hidden[c,h] (split-K slabs), db[v] = sum_c G[c,v].
+// 4 waves = 2 (M) x 2 (N), workgroup tile 256 v x 256 h, wave 128 x 128 = 16 accumulator tiles (256
+// registers).  Both operands are row-major with K (the cell) as the ROW, three planes each:
+//  * HBM -> LDS by LDS-DMA (no VGPRs), ring of 3 stages of 16 cells x (256 v + 256 h) x 3 planes = 48 KiB;
+//    wave w fills operand tile w (w = 0,1: the two 128-column halves of the G tile, 2,3: of the hidden
+//    tile), 12 DMAs of 1 KiB (4 rows x 256 B) per stage;
+//  * LDS -> VGPR by ds_read_b64_tr_b16 (hardware 4x16 transpose read, cdna_hip_programming.md T10): two
+//    reads give a lane its 8 consecutive cells of one column = the MFMA fragment;
+//  * tile image (b) of T10: 256-byte rows, 16-byte chunk ch of row r at 16*(ch ^ swz(r)),
+//    swz(r) = ((r&3)<<2) | ((r>>2)&3); the DMA writes LDS linearly, so the swizzle is applied on the
+//    SOURCE side: LDS chunk position p of row r is fetched from global chunk p ^ swz(r).
+// One k-step = 16 cells = 6 products x 16 tiles = 96 MFMAs (3072 matrix-pipe cycles) against 48 KiB staged.
+// Per k-step: counted vmcnt + one barrier publish stage ks (and prove stage ks-1 read by every wave), the
+// DMAs of stage ks+2 go into the slot of ks-1 threaded through the MFMAs, fragment reads run one product
+// ahead of their MFMAs.  Product order ah.bh, am.bh, am.bm, ah.bm, al.bh, ah.bl keeps at most five of the
+// six 16-register fragment sets live.
+// ---------------------------------------------------------------------------------------
+#define XW_ROWS 16
+#define XW_NST 3
+#define XW_SLOT 49152
+#define XW_GRAN 32  // granule of the live-row table (shared with the bf16 route: 2 k-steps)
+
+struct X3Frag { u32x2 lo[4], hi[4]; };  // 4 tiles: cells 0-3 / 4-7 of a lane's 8
+
+__global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) char s_ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    const int H = a.H, V = a.V;
+    const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
+    const int tiles = n_vblk * n_hblk;
+    const int total = tiles * a.n_split;
+    int id = blockIdx.x;  // XCD-aware remap: the tiles of one split share an XCD's L2
+    {
+        const int q8 = total / 8, r8 = total % 8, x = id % 8;
+        id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + id / 8;
+    }
+    const int tile = id % tiles, split = id / tiles;
+    const int vb = tile / n_hblk, hb = tile % n_hblk;
+    const long *tab = a.dw_tab;
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
+    // db: column sums of G from the A fragments (fp32 adds of the unpacked bf16 pieces), all three planes.
+    // The work (4 M tiles of each of this v block's two wm halves) is spread over the waves of the h
+    // blocks 0 and 1: share = (hb, wn) handles M tile `share` (n_hblk >= 2) or tiles {wn, wn+2}.
+    const int n_share = n_hblk >= 2 ? 4 : 2;
+    const int share = n_hblk >= 2 ? (hb & 1) * 2 + wn : wn;
+    const bool do_b = hb < 2;  // workgroup-uniform
+    float dbl[2] = {0.f, 0.f};
+
+    if (g_hi > g_lo) {
+        // ---- DMA source of this wave's operand tile
+        const bool is_g = wave < 2;
+        int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
+        if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
+        // plane p of this wave's operand: base pointer (wave-uniform) and row stride in bytes
+        const char *pbase[3];
+        long rstride[3];
+        if (is_g) {
+            pbase[0] = (const char *)a.logits + 4L * col0;        // hi: first 64 bytes of each 128-byte chunk
+            pbase[1] = (const char *)a.logits + 4L * col0 + 64;   // mid: last 64
+            pbase[2] = (const char *)a.g_lo + 2L * col0;
+            rstride[0] = rstride[1] = 4L * V; rstride[2] = 2L * V;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { pbase[p] = (const char *)(a.hidden + p * a.plane_stride) + 2L * col0; rstride[p] = 2L * H; }
+        }
+        // DMA i (0..3) of a plane's 16 rows: rows 4i .. 4i+3; lane L: row 4i + (L>>4), LDS chunk position L&15
+        // <- global chunk jg = (L&15) ^ swz(row), swz = ((L>>4)<<2) | (i&3)
+        int soff[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jg = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
+                // interleaved planes (G hi / mid): chunk jg of the plane is 16 bytes at 128*(jg>>2) + 16*(jg&3)
+                const int cb = (is_g && p < 2) ? 128 * (jg >> 2) + 16 * (jg & 3) : 16 * jg;
+                soff[p][i] = (int)((4 * i + (lane >> 4)) * rstride[p]) + cb;
+            }
+        long row_first = 0;  // first cell of the range being walked
+        auto dma_piece = [&](long ks, int slot, int n) {  // n = 0..11: plane n>>2, piece n&3
+            const int p = n >> 2, i = n & 3;
+            __builtin_amdgcn_global_load_lds((const void *)(pbase[p] + (row_first + ks * XW_ROWS) * rstride[p] + soff[p][i]),
+                                             (lds_vptr)(s_ring + slot * XW_SLOT + wave * 12288 + p * 4096 + 1024 * i), 16, 0, 0);
+        };
+        // ---- transposed fragment reads.  Fragment of 32-column tile m: lane (g = lane>>4, q = (lane&15)>>2,
+        // p = lane&3) reads rows 8(g>>1) + 4sec + q at chunk 4m + 2(g&1) + (p>>1), +8(p&1) bytes, sec = 0,1.
+        const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hh = g >> 1;
+        int foff[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                const int row = 8 * hh + 4 * sec + q;
+                const int ch = 4 * m + 2 * (g & 1) + (pp >> 1);
+                const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+                foff[m][sec] = 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+            }
+        const int lds0 = (int)(size_t)(lds_vptr)s_ring;
+        const int a_tile = lds0 + wm * 12288, b_tile = lds0 + 24576 + wn * 12288;
+        // 8 transposed reads of one plane of one operand (inline asm: hipcc guards every LDS read it can
+        // see behind an LDS-DMA with vmcnt(0)); results are used only after landed<>() named them
+        auto reads = [&](X3Frag &f, int base) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo[m]) : "v"(base + foff[m][0]));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi[m]) : "v"(base + foff[m][1]));
+            }
+        };
+#define X3_LANDED(f, N)                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                     \
+                 : "+v"(f.lo[0]), "+v"(f.lo[1]), "+v"(f.lo[2]), "+v"(f.lo[3]), "+v"(f.hi[0]), "+v"(f.hi[1]),     \
+                   "+v"(f.hi[2]), "+v"(f.hi[3])                                                                  \
+                 :: "memory")
+        // 16 MFMAs of one product with 2 DMA pieces (n0, n0+1) of stage `dst` threaded through them
+        auto product = [&](const X3Frag &fa_, const X3Frag &fb_, long dst, int dslot, int n0) {
+            u32x4 fa[4], fb[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                fa[m] = u32x4{fa_.lo[m][0], fa_.lo[m][1], fa_.hi[m][0], fa_.hi[m][1]};
+                fb[m] = u32x4{fb_.lo[m][0], fb_.lo[m][1], fb_.hi[m][0], fb_.hi[m][1]};
+            }
+#pragma unroll
+            for (int qm = 0; qm < 4; ++qm) {
+#pragma unroll
+                for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x3_mfma(fa[qm], fb[qn], acc[qm][qn]);
+                if (qm == 1) dma_piece(dst, dslot, n0);
+                if (qm == 3) dma_piece(dst, dslot, n0 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto bias_dots = [&](const X3Frag &f) {
+            if (!do_b) return;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int m = n_share == 4 ? share : share + 2 * k;
+                if (n_share == 4 && k == 1) break;
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm)
+                    if (mm == m) {
+                        // plain fp32 adds of the unpacked halves (v_dot2c_f32_bf16 with a pair of ones, the
+                        // bf16 route's form, is NOT fp32-exact: measured 9e-3 relative on db)
+                        dbl[k] += (x3_lo(f.lo[mm][0]) + x3_hi(f.lo[mm][0])) + (x3_lo(f.lo[mm][1]) + x3_hi(f.lo[mm][1]));
+                        dbl[k] += (x3_lo(f.hi[mm][0]) + x3_hi(f.hi[mm][0])) + (x3_lo(f.hi[mm][1]) + x3_hi(f.hi[mm][1]));
+                    }
+            }
+        };
+
+        int ub = 0;
+        while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;
+        for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
+            const long cum0 = tab[B + 1 + ub], cum1 = ub + 1 < B ? tab[B + 1 + ub + 1] : nlive;
+            const long ge = cum1 < g_hi ? cum1 : g_hi;
+            if (ge <= gq) continue;
+            const long nks = 2 * (ge - gq);  // 16-cell k-steps of this range
+            row_first = (tab[ub] + (gq - cum0)) * XW_GRAN;
+            gq = ge;
+#pragma unroll
+            for (int n = 0; n < 12; ++n) dma_piece(0, 0, n);
+#pragma unroll
+            for (int n = 0; n < 12; ++n) dma_piece(1, 1, n);
+            for (long ks = 0; ks < nks; ++ks) {
+                const int slot = (int)(ks % 3), dslot = (int)((ks + 2) % 3);
+                // stage ks landed (the 12 younger pieces of ks+1 may still fly); every wave is past its
+                // reads of stage ks-1, whose slot the DMAs below refill
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                x3_lds_barrier();
+                const int ab = a_tile + slot * XW_SLOT, bb = b_tile + slot * XW_SLOT;
+                X3Frag Ah, Bh, Am, Bm, Al, Bl;
+                reads(Ah, ab);
+                reads(Bh, bb);
+                reads(Am, ab + 4096);
+                X3_LANDED(Ah, 8);
+                X3_LANDED(Bh, 8);
+                product(Ah, Bh, ks + 2, dslot, 0);
+                reads(Bm, bb + 4096);
+                X3_LANDED(Am, 8);
+                product(Am, Bh, ks + 2, dslot, 2);
+                reads(Al, ab + 8192);
+                X3_LANDED(Bm, 8);
+                product(Am, Bm, ks + 2, dslot, 4);
+                reads(Bl, bb + 8192);
+                product(Ah, Bm, ks + 2, dslot, 6);
+                X3_LANDED(Al, 8);
+                product(Al, Bh, ks + 2, dslot, 8);
+                X3_LANDED(Bl, 0);
+                product(Ah, Bl, ks + 2, dslot, 10);
+                bias_dots(Ah); bias_dots(Am); bias_dots(Al);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the ring
+            x3_lds_barrier();                                  // is refilled / the kernel exits
+        }
+    }
+
+    // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r of tile
+    // (qm,qn): v = v0 + 32qm + (r&3) + 8(r>>2) + 4half, h = h0 + 32qn + (lane&31).
+    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
+    float *sw = a.slab_w + (long)split * V * H;
+#pragma unroll
+    for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = v0 + 32 * qm + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (v < V) {
+#pragma unroll
+                for (int qn = 0; qn < 4; ++qn) {
+                    const int h = h0 + 32 * qn + (lane & 31);
+                    if (h < H) sw[(long)v * H + h] = acc[qm][qn][r];
+                }
+            }
+        }
+    if (do_b) {  // lane (v = l&31, half) summed the cells 8*half .. 8*half+7 of every k-step
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (n_share == 4 && k == 1) break;
+            const int m = n_share == 4 ? share : share + 2 * k;
+            const float t = dbl[k] + __shfl_xor(dbl[k], 32, 64);
+            const int v = v0 + 32 * m + (lane & 31);
+            if (half == 0 && v < V) a.slab_b[(long)split * V + v] = t;
+        }
+    }
+}
+
+void launch_dw_x3(const X3Args &a, hipStream_t st)
+{
+    launch_dw_table(a.logit_lens, a.B, a.T, a.U1, XW_GRAN, a.dw_tab, st);
+    const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
+    static bool attr_set[16] = {false};  // > 64 KiB of dynamic LDS: opt-in once per device (read-mostly fact)
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_dw_x3, hipFuncAttributeMaxDynamicSharedMemorySize, XW_NST * XW_SLOT);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_dw_x3, dim3(tiles * a.n_split), dim3(256), XW_NST * XW_SLOT, st, a);
+}
+
+// ---- not built yet: the engine routes these stages to the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*)
+bool x3_fwd_ok(int, int, int) { return false; }
+bool x3_dhidden_ok(int, int, int) { return false; }
+size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)3 * ((V + 511) / 512 * 512) * H * 2; }
+size_t x3_wpack_dh_bytes(int H, int V) { return (size_t)3 * ((H + 511) / 512 * 512) * V * 2; }
+void launch_x3_pack_w(const X3Args &, hipStream_t) {}
+void launch_joint_fwd_x3(const X3Args &, hipStream_t) {}
+void launch_dhidden_x3(const X3Args &, hipStream_t) {}

@@ -19,8 +19,10 @@ LIB_PATH = os.environ.get("RNNT_ENGINE_LIB") or os.path.join(_CSRC, "librnnt_eng
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1  # bf16 GEMM operands, fp32 accumulate, fp16 logits (workspace), fp32/fp64 loss; fp32 tensors at the boundary
+DTYPE_F32_BF16X3 = 2  # fp32-accurate products as six bf16 MFMA products of 3-way split operands (x3.hip)
 _DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, DTYPE_F32: DTYPE_F32,
-           "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, DTYPE_BF16: DTYPE_BF16}
+           "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, DTYPE_BF16: DTYPE_BF16,
+           "bf16x3": DTYPE_F32_BF16X3, "f32_bf16x3": DTYPE_F32_BF16X3, DTYPE_F32_BF16X3: DTYPE_F32_BF16X3}
 
 
 class _Int32:
@@ -83,7 +85,7 @@ def dtype_code(dtype):
     try:
         return _DTYPES[dtype]
     except (KeyError, TypeError):
-        raise ValueError(f"rnnt_amd: unsupported compute dtype {dtype!r} (fp32 or bf16)") from None
+        raise ValueError(f"rnnt_amd: unsupported compute dtype {dtype!r} (fp32, bf16 or bf16x3)") from None
 _lock = threading.Lock()
 _lib = None
 _workspaces = {}
@@ -109,6 +111,8 @@ VARIANT_SEPARATE_G = 32
 VARIANT_SEPARATE_HIDDEN = 64
 VARIANT_FWD_LDS_RING = 128
 VARIANT_FWD_ONE_WG_PER_TILE = 256
+VARIANT_X3_FP32_FWD = 4096  # bf16x3 route: this stage on the fp32 route's kernel (isolation checks; not bit-identical)
+VARIANT_X3_FP32_DH = 8192
 STAGES_ALL = 255
 STAGES_FORWARD = 7  # operand producers + joint-forward GEMM + lattice sweep: costs only
 
@@ -117,7 +121,8 @@ class WsLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "logits", "hidden", "denom_s", "lpb_s", "lpe_s", "alpha_s", "beta_s", "coef", "wpack",
         "enc_copy", "slab_enc", "slab_pred", "slab_w", "slab_b", "counters", "total", "rows_pad")] + [
-        (n, ctypes.c_int) for n in ("n_ublk", "n_ttile", "n_split", "D")]
+        (n, ctypes.c_int) for n in ("n_ublk", "n_ttile", "n_split", "D")] + [
+        (n, ctypes.c_size_t) for n in ("g_lo", "aux")]
 
 
 def build(force: bool = False) -> str:

@@ -12,6 +12,10 @@ import torch
 from . import engine
 
 _PAD_NEG = -1.0e30  # bias of padded vocabulary columns: exp() underflows to exactly 0
+# bf16x3 route (pads V to a multiple of 128, so a lane's whole column group can be padding): -1e30 next to
+# itself loses the softmax's max subtraction to fp32 rounding (ulp(1.44e30) = 7.6e22 -> exp2 overflows);
+# -1e4 still underflows to exactly 0 against any real logit (> -9.9e3) and subtracts from itself exactly
+_PAD_NEG_WIDE = -1.0e4
 
 
 def _check_loss_args(T, U1, V, B, targets, logit_lengths, target_lengths, blank, reduction,
@@ -89,18 +93,19 @@ def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=-1, clamp=-1
     return costs
 
 
-def _pad_hv(enc, pred, W, bias):
-    """Zero-pad H to a multiple of 4 and V to a multiple of 4 (engine requirement); padded
-    vocabulary rows get bias -1e30 so they carry zero probability and zero gradient."""
+def _pad_hv(enc, pred, W, bias, mult=4):
+    """Zero-pad H and V to multiples of `mult` (engine requirement: 4 on the fp32 route, 128 on the
+    bf16x3 route); padded vocabulary rows get bias -1e30 so they carry zero probability and zero
+    gradient, padded hidden columns are tanh(0) = 0 against zero weights."""
     H, V = W.shape[1], W.shape[0]
-    ph, pv = (-H) % 4, (-V) % 4
+    ph, pv = (-H) % mult, (-V) % mult
     if ph:
         enc = torch.nn.functional.pad(enc, (0, ph))
         pred = torch.nn.functional.pad(pred, (0, ph))
         W = torch.nn.functional.pad(W, (0, ph))
     if pv:
         W = torch.nn.functional.pad(W, (0, 0, 0, pv))
-        bias = torch.nn.functional.pad(bias, (0, pv), value=_PAD_NEG)
+        bias = torch.nn.functional.pad(bias, (0, pv), value=_PAD_NEG if mult <= 4 else _PAD_NEG_WIDE)
     return enc, pred, W, bias, H, V
 
 
@@ -190,7 +195,10 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
     enc, pred, W and bias.  enc [B,T,H] (any strides), pred [B,U+1,H], W [V,H], bias [V].
     `grad_scale` overrides the reduction factor (1/B_global when the batch is sharded).
     `dtype="bf16"` (BASELINE config 3): tensors stay fp32, the three GEMMs run on bf16-rounded
-    operands with fp32 accumulation; needs H % 128 == 0, V % 128 == 0."""
+    operands with fp32 accumulation; needs H % 128 == 0, V % 128 == 0.
+    `dtype="bf16x3"`: fp32-accurate results (same 1e-4 bar as "fp32") from the bf16 matrix pipes — operands
+    split three ways, six bf16 products per fp32 product (include/rnnt_engine.h RNNT_DTYPE_F32_BF16X3);
+    any H, V (zero-padded to multiples of 128 here)."""
     if reduction not in ("mean", "sum"):
         if reduction == "none":
             raise NotImplementedError(
@@ -212,7 +220,7 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
     if code == engine.DTYPE_BF16:  # no host-side padding on this route: the C side validates
         enc_p, pred_p, W_p, bias_p = enc, pred, W, bias
     else:
-        enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias)
+        enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias, 128 if code == engine.DTYPE_F32_BF16X3 else 4)
     scale = float(grad_scale) if grad_scale is not None else (1.0 / B if reduction == "mean" else 1.0)
     # validation / eval (reference rnnt/train.py:170-201 runs the model under no_grad): costs only
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (enc, pred, W, bias))

@@ -172,3 +172,20 @@ def test_bf16_rounding_point_oracle_is_close_to_exact():
     for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
         assert_close_grad(k, a[k], b[k], rtol=BF16_GRAD_RTOL_EXACT)
         assert np.abs(a[k] - b[k]).max() > 0  # the rounding really happens
+
+
+def test_parallel_fp32_loss_of_the_cpu_baseline_matches_the_oracle():
+    """bench.py's cpu_baseline times rnnt_oracle_loss_par_f32 (OpenMP over (b,t,u) rows, expf/logf); it is
+    the same arithmetic as the ground-truth instantiations: costs and gradients agree with the fp64 oracle
+    to fp32 accuracy on ragged inputs, blank = -1."""
+    rng = np.random.default_rng(3)
+    B, T, U1, V = 3, 19, 7, 33
+    logits = rng.standard_normal((B, T, U1, V)).astype(np.float32) * 2
+    targets = rng.integers(0, V - 1, (B, U1 - 1)).astype(np.int32)
+    ll = np.array([19, 11, 1], dtype=np.int32)
+    tl = np.array([6, 0, 3], dtype=np.int32)
+    c64, g64 = cpu_oracle.rnnt_loss(logits, targets, ll, tl, dtype=np.float64)
+    c32, g32 = cpu_oracle.rnnt_loss_par_f32(logits, targets, ll, tl)
+    np.testing.assert_allclose(c32, c64, rtol=2e-5)
+    assert np.abs(g32 - g64).max() < 5e-5
+    assert np.abs(g32[1, 11:]).max() == 0 and np.abs(g32[2, :, 4:]).max() == 0  # dead cells
