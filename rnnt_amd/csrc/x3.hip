@@ -164,13 +164,25 @@ void launch_x3_zero_padding(const X3Args &a, hipStream_t st)
 // ---------------------------------------------------------------------------------------
 #define XW_ROWS 16
 #define XW_NST 3
-#define XW_SLOT 49152
+#define XW_PLANE 4096          // one operand tile of one plane: 16 rows x 256 B
+#define XW_STAGE (3 * XW_PLANE)  // one stage of one operand tile
+#define XW_TILE (XW_NST * XW_STAGE)  // ring of one operand tile: [stage][plane][16 x 256 B] = 36 KiB
 #define XW_GRAN 32  // granule of the live-row table (shared with the bf16 route: 2 k-steps)
 
 struct X3Frag { u32x2 lo[4], hi[4]; };  // 4 tiles: cells 0-3 / 4-7 of a lane's 8
+#define X3_LANDED(f, N)                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                     \
+                 : "+v"(f.lo[0]), "+v"(f.lo[1]), "+v"(f.lo[2]), "+v"(f.lo[3]), "+v"(f.hi[0]), "+v"(f.hi[1]),     \
+                   "+v"(f.hi[2]), "+v"(f.hi[3])                                                                  \
+                 :: "memory")
+template <int N> struct X3Int { static constexpr int value = N; };
 
 __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
 {
+    // LDS: 4 operand tiles (wave w fills tile w: 0,1 = the 128-column halves of the G tile, 2,3 = of the hidden
+    // tile), each a ring [stage][plane][16 x 256 B]: every fragment read of a wave is one of 8 base registers
+    // plus an immediate (stage, plane) offset < 64 KiB — no address arithmetic in the loop (one wave per SIMD
+    // issues ~1 instruction per 4-5 cycles: every instruction between two MFMAs counts)
     extern __shared__ __attribute__((aligned(1024))) char s_ring[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,21 +211,27 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
         for (int qn = 0; qn < 4; ++qn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
-    // db: column sums of G from the A fragments (fp32 adds of the unpacked bf16 pieces), all three planes.
-    // The work (4 M tiles of each of this v block's two wm halves) is spread over the waves of the h
-    // blocks 0 and 1: share = (hb, wn) handles M tile `share` (n_hblk >= 2) or tiles {wn, wn+2}.
-    const int n_share = n_hblk >= 2 ? 4 : 2;
-    const int share = n_hblk >= 2 ? (hb & 1) * 2 + wn : wn;
+    // db[v] = sum_c G[c,v] rides the matrix pipe: one more MFMA per plane and k-step against a B fragment of
+    // ones, for ONE of the wave's 4 M tiles, into a 17th accumulator tile (VGPRs).  The 8 M tiles of a v block
+    // are shared out over the waves of the h blocks 0 and 1: (hb, wn) -> M tile `bsel0` of this wave's wm half
+    // (one h block, H <= 256: each wave takes two tiles, bsel0 and bsel0 + 2).  (fp32 adds of unpacked halves
+    // cost ~50 VALU per k-step; v_dot2c_f32_bf16 with a pair of ones — the bf16 route's form — is not
+    // fp32-exact: 9e-3 relative error on db.)
+    // Two tiles share the one accumulator through column SELECTORS: a B fragment that is ones in column j
+    // only puts the row sums of its M tile into column j of the product.
     const bool do_b = hb < 2;  // workgroup-uniform
-    float dbl[2] = {0.f, 0.f};
+    const int bsel0 = n_hblk >= 2 ? (hb & 1) * 2 + wn : wn;
+    f32x16 dacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+    const unsigned sel0 = (lane & 31) == 0 ? 0x3f803f80u : 0u, sel1 = (lane & 31) == 1 ? 0x3f803f80u : 0u;
 
     if (g_hi > g_lo) {
         // ---- DMA source of this wave's operand tile
         const bool is_g = wave < 2;
         int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
         if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
-        // plane p of this wave's operand: base pointer (wave-uniform) and row stride in bytes
-        const char *pbase[3];
+        const char *pbase[3];  // plane p of this wave's operand: base pointer (wave-uniform), row stride in bytes
         long rstride[3];
         if (is_g) {
             pbase[0] = (const char *)a.logits + 4L * col0;        // hi: first 64 bytes of each 128-byte chunk
@@ -237,15 +255,11 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
                 soff[p][i] = (int)((4 * i + (lane >> 4)) * rstride[p]) + cb;
             }
         long row_first = 0;  // first cell of the range being walked
-        auto dma_piece = [&](long ks, int slot, int n) {  // n = 0..11: plane n>>2, piece n&3
-            const int p = n >> 2, i = n & 3;
-            __builtin_amdgcn_global_load_lds((const void *)(pbase[p] + (row_first + ks * XW_ROWS) * rstride[p] + soff[p][i]),
-                                             (lds_vptr)(s_ring + slot * XW_SLOT + wave * 12288 + p * 4096 + 1024 * i), 16, 0, 0);
-        };
         // ---- transposed fragment reads.  Fragment of 32-column tile m: lane (g = lane>>4, q = (lane&15)>>2,
         // p = lane&3) reads rows 8(g>>1) + 4sec + q at chunk 4m + 2(g&1) + (p>>1), +8(p&1) bytes, sec = 0,1.
         const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hh = g >> 1;
-        int foff[4][2];
+        const int lds0 = (int)(size_t)(lds_vptr)s_ring;
+        int abase[4][2], bbase[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -253,55 +267,127 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
                 const int row = 8 * hh + 4 * sec + q;
                 const int ch = 4 * m + 2 * (g & 1) + (pp >> 1);
                 const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-                foff[m][sec] = 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+                const int fo = 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+                abase[m][sec] = lds0 + wm * XW_TILE + fo;
+                bbase[m][sec] = lds0 + (2 + wn) * XW_TILE + fo;
             }
-        const int lds0 = (int)(size_t)(lds_vptr)s_ring;
-        const int a_tile = lds0 + wm * 12288, b_tile = lds0 + 24576 + wn * 12288;
-        // 8 transposed reads of one plane of one operand (inline asm: hipcc guards every LDS read it can
-        // see behind an LDS-DMA with vmcnt(0)); results are used only after landed<>() named them
-        auto reads = [&](X3Frag &f, int base) {
+        int sbase[2][2];  // db: fragment bases of the M tile(s) this wave sums (bsel0, and bsel0 + 2 with one h block)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo[m]) : "v"(base + foff[m][0]));
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi[m]) : "v"(base + foff[m][1]));
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                const int m = (bsel0 + 2 * k) & 3;
+                const int row = 8 * hh + 4 * sec + q;
+                const int ch = 4 * m + 2 * (g & 1) + (pp >> 1);
+                const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+                sbase[k][sec] = lds0 + wm * XW_TILE + 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
             }
-        };
-#define X3_LANDED(f, N)                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                     \
-                 : "+v"(f.lo[0]), "+v"(f.lo[1]), "+v"(f.lo[2]), "+v"(f.lo[3]), "+v"(f.hi[0]), "+v"(f.hi[1]),     \
-                   "+v"(f.hi[2]), "+v"(f.hi[3])                                                                  \
-                 :: "memory")
-        // 16 MFMAs of one product with 2 DMA pieces (n0, n0+1) of stage `dst` threaded through them
-        auto product = [&](const X3Frag &fa_, const X3Frag &fb_, long dst, int dslot, int n0) {
-            u32x4 fa[4], fb[4];
+
+        // one k-step on ring stage ST (compile-time: every LDS offset is an immediate)
+        auto kstep = [&](auto st_c, long ks, f32x16 &dacc) {
+            constexpr int ST = decltype(st_c)::value, DST = (ST + 2) % 3;
+            // the 16 rows of stage ks+2 as three raw buffers (wave-uniform base: scalar arithmetic only; the
+            // per-lane part of a DMA address is the 32-bit soff)
+            __amdgpu_buffer_rsrc_t rs[3];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                fa[m] = u32x4{fa_.lo[m][0], fa_.lo[m][1], fa_.hi[m][0], fa_.hi[m][1]};
-                fb[m] = u32x4{fb_.lo[m][0], fb_.lo[m][1], fb_.hi[m][0], fb_.hi[m][1]};
-            }
+            for (int p = 0; p < 3; ++p)
+                rs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (ks + 2) * XW_ROWS) * rstride[p]), 0,
+                                                          (int)(XW_ROWS * rstride[p]), 0x00020000);
+            auto dma_piece = [&](auto n_c) {  // piece n of stage ks+2 -> ring stage DST: plane n>>2, rows 4(n&3)..
+                constexpr int n = decltype(n_c)::value, p = n >> 2, i = n & 3;
+                if (RNNT_XP(a.flags, 8192)) return;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + wave * XW_TILE + DST * XW_STAGE + p * XW_PLANE + 1024 * i),
+                                                         16, soff[p][i], 0, 0, 0);
+            };
+            // 8 transposed reads of plane P of the A / B operand (inline asm: hipcc guards every LDS read it can
+            // see behind an LDS-DMA with vmcnt(0)); results are used only after X3_LANDED named them
+            auto reads = [&](X3Frag &f, const int (&base)[4][2], auto p_c) {
+                constexpr int off = ST * XW_STAGE + decltype(p_c)::value * XW_PLANE;
+                if (RNNT_XP(a.flags, 4096)) return;
 #pragma unroll
-            for (int qm = 0; qm < 4; ++qm) {
+                for (int m = 0; m < 4; ++m) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo[m]) : "v"(base[m][0]), "n"(off));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi[m]) : "v"(base[m][1]), "n"(off));
+                }
+            };
+            // 16 MFMAs of one product with DMA pieces N0, N0+1 threaded through them
+            auto product = [&](const X3Frag &fa_, const X3Frag &fb_, auto n0_c) {
+                constexpr int N0 = decltype(n0_c)::value;
+                u32x4 fa[4], fb[4];
 #pragma unroll
-                for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x3_mfma(fa[qm], fb[qn], acc[qm][qn]);
-                if (qm == 1) dma_piece(dst, dslot, n0);
-                if (qm == 3) dma_piece(dst, dslot, n0 + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto bias_dots = [&](const X3Frag &f) {
-            if (!do_b) return;
+                for (int m = 0; m < 4; ++m) {
+                    fa[m] = u32x4{fa_.lo[m][0], fa_.lo[m][1], fa_.hi[m][0], fa_.hi[m][1]};
+                    fb[m] = u32x4{fb_.lo[m][0], fb_.lo[m][1], fb_.hi[m][0], fb_.hi[m][1]};
+                }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int m = n_share == 4 ? share : share + 2 * k;
-                if (n_share == 4 && k == 1) break;
+                for (int qm = 0; qm < 4; ++qm) {
+                    if (!RNNT_XP(a.flags, 1024)) {
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm)
-                    if (mm == m) {
-                        // plain fp32 adds of the unpacked halves (v_dot2c_f32_bf16 with a pair of ones, the
-                        // bf16 route's form, is NOT fp32-exact: measured 9e-3 relative on db)
-                        dbl[k] += (x3_lo(f.lo[mm][0]) + x3_hi(f.lo[mm][0])) + (x3_lo(f.lo[mm][1]) + x3_hi(f.lo[mm][1]));
-                        dbl[k] += (x3_lo(f.hi[mm][0]) + x3_hi(f.hi[mm][0])) + (x3_lo(f.hi[mm][1]) + x3_hi(f.hi[mm][1]));
+                        for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x3_mfma(fa[qm], fb[qn], acc[qm][qn]);
                     }
+                    if (qm == 1) dma_piece(X3Int<N0>{});
+                    if (qm == 3) dma_piece(X3Int<N0 + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // db: the selected M tile's fragment of plane P is read once more through its own base registers (a
+            // run-time choice among the wave's four fragment sets would be branches or selects around the MFMA)
+            auto bias_read = [&](u32x2 &lo, u32x2 &hi, auto p_c, int k) {
+                constexpr int off = ST * XW_STAGE + decltype(p_c)::value * XW_PLANE;
+                const int b0 = sbase[k][0], b1 = sbase[k][1];  // (locals: asm operands cannot name a capture of the enclosing generic lambda)
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(b0), "n"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(b1), "n"(off));
+            };
+            auto bias_mfma = [&](u32x2 &lo, u32x2 &hi, f32x16 &dacc, int k) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) :: "memory");
+                const u32x4 fa = {lo[0], lo[1], hi[0], hi[1]};
+                const unsigned sv = k ? sel1 : sel0;
+                const u32x4 sel = {sv, sv, sv, sv};
+                // accumulator in VGPRs, spelled as asm: left to hipcc, the 17th tile is shuttled through the
+                // (full) AGPR file around every one of these MFMAs (672 v_accvgpr moves per k-step)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dacc) : "v"(fa), "v"(sel));
+            };
+            // stage ks landed (the 12 younger pieces of ks+1 may still fly); every wave is past its
+            // reads of stage ks-1, whose ring stage the DMAs below refill
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            x3_lds_barrier();
+            X3Frag Ah, Bh, Am, Bm, Al, Bl;  // at most four of the six sets are live at a time (+ one landing)
+            u32x2 dl[3], dh[3];
+            reads(Ah, abase, X3Int<0>{});
+            reads(Bh, bbase, X3Int<0>{});
+            reads(Am, abase, X3Int<1>{});
+            X3_LANDED(Ah, 8);
+            X3_LANDED(Bh, 8);
+            product(Ah, Bh, X3Int<0>{});
+            reads(Bm, bbase, X3Int<1>{});
+            X3_LANDED(Am, 8);
+            product(Am, Bh, X3Int<2>{});
+            X3_LANDED(Bm, 0);
+            product(Am, Bm, X3Int<4>{});
+            reads(Al, abase, X3Int<2>{});
+            if (do_b) { bias_read(dl[0], dh[0], X3Int<0>{}, 0); bias_read(dl[1], dh[1], X3Int<1>{}, 0); bias_read(dl[2], dh[2], X3Int<2>{}, 0); }
+            product(Ah, Bm, X3Int<6>{});
+            reads(Bl, bbase, X3Int<2>{});
+            X3_LANDED(Al, 8);
+            product(Al, Bh, X3Int<8>{});
+            X3_LANDED(Bl, 0);
+            product(Ah, Bl, X3Int<10>{});
+            if (do_b && !RNNT_XP(a.flags, 2048)) {
+                bias_mfma(dl[0], dh[0], dacc, 0); bias_mfma(dl[1], dh[1], dacc, 0); bias_mfma(dl[2], dh[2], dacc, 0);
+                if (n_hblk < 2) {  // one h block: the wave's second tile (column 1 of the selector product), H <= 256 only
+                    bias_read(dl[0], dh[0], X3Int<0>{}, 1); bias_read(dl[1], dh[1], X3Int<1>{}, 1); bias_read(dl[2], dh[2], X3Int<2>{}, 1);
+                    bias_mfma(dl[0], dh[0], dacc, 1); bias_mfma(dl[1], dh[1], dacc, 1); bias_mfma(dl[2], dh[2], dacc, 1);
+                }
+            }
+        };
+        auto dma_stage = [&](long ks, int st) {  // pipeline prologue: all 12 pieces of stage ks
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int p = n >> 2, i = n & 3;
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(pbase[p] + (row_first + ks * XW_ROWS) * rstride[p]), 0, (int)(XW_ROWS * rstride[p]), 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(s_ring + wave * XW_TILE + st * XW_STAGE + p * XW_PLANE + 1024 * i),
+                                                         16, soff[p][i], 0, 0, 0);
             }
         };
 
@@ -314,37 +400,15 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
             const long nks = 2 * (ge - gq);  // 16-cell k-steps of this range
             row_first = (tab[ub] + (gq - cum0)) * XW_GRAN;
             gq = ge;
-#pragma unroll
-            for (int n = 0; n < 12; ++n) dma_piece(0, 0, n);
-#pragma unroll
-            for (int n = 0; n < 12; ++n) dma_piece(1, 1, n);
-            for (long ks = 0; ks < nks; ++ks) {
-                const int slot = (int)(ks % 3), dslot = (int)((ks + 2) % 3);
-                // stage ks landed (the 12 younger pieces of ks+1 may still fly); every wave is past its
-                // reads of stage ks-1, whose slot the DMAs below refill
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                x3_lds_barrier();
-                const int ab = a_tile + slot * XW_SLOT, bb = b_tile + slot * XW_SLOT;
-                X3Frag Ah, Bh, Am, Bm, Al, Bl;
-                reads(Ah, ab);
-                reads(Bh, bb);
-                reads(Am, ab + 4096);
-                X3_LANDED(Ah, 8);
-                X3_LANDED(Bh, 8);
-                product(Ah, Bh, ks + 2, dslot, 0);
-                reads(Bm, bb + 4096);
-                X3_LANDED(Am, 8);
-                product(Am, Bh, ks + 2, dslot, 2);
-                reads(Al, ab + 8192);
-                X3_LANDED(Bm, 8);
-                product(Am, Bm, ks + 2, dslot, 4);
-                reads(Bl, bb + 8192);
-                product(Ah, Bm, ks + 2, dslot, 6);
-                X3_LANDED(Al, 8);
-                product(Al, Bh, ks + 2, dslot, 8);
-                X3_LANDED(Bl, 0);
-                product(Ah, Bl, ks + 2, dslot, 10);
-                bias_dots(Ah); bias_dots(Am); bias_dots(Al);
+            dma_stage(0, 0);
+            dma_stage(1, 1);
+            for (long ks = 0;;) {  // the ring stage of a k-step is ks % 3: unrolled by 3
+                if (ks >= nks) break;
+                kstep(X3Int<0>{}, ks, dacc); ++ks;
+                if (ks >= nks) break;
+                kstep(X3Int<1>{}, ks, dacc); ++ks;
+                if (ks >= nks) break;
+                kstep(X3Int<2>{}, ks, dacc); ++ks;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the ring
             x3_lds_barrier();                                  // is refilled / the kernel exits
@@ -368,14 +432,12 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
                 }
             }
         }
-    if (do_b) {  // lane (v = l&31, half) summed the cells 8*half .. 8*half+7 of every k-step
+    if (do_b && (lane & 31) < (n_hblk >= 2 ? 1 : 2)) {  // column k of the selector products: lanes k / 32+k store
+        const int m = bsel0 + 2 * (lane & 31);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (n_share == 4 && k == 1) break;
-            const int m = n_share == 4 ? share : share + 2 * k;
-            const float t = dbl[k] + __shfl_xor(dbl[k], 32, 64);
-            const int v = v0 + 32 * m + (lane & 31);
-            if (half == 0 && v < V) a.slab_b[(long)split * V + v] = t;
+        for (int r = 0; r < 16; ++r) {
+            const int v = v0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (v < V) a.slab_b[(long)split * V + v] = dacc[r];
         }
     }
 }
@@ -388,10 +450,10 @@ void launch_dw_x3(const X3Args &a, hipStream_t st)
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
     if (dev < 0 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void *)k_dw_x3, hipFuncAttributeMaxDynamicSharedMemorySize, XW_NST * XW_SLOT);
+        (void)hipFuncSetAttribute((const void *)k_dw_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW_TILE);
         if (dev >= 0) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_dw_x3, dim3(tiles * a.n_split), dim3(256), XW_NST * XW_SLOT, st, a);
+    hipLaunchKernelGGL(k_dw_x3, dim3(tiles * a.n_split), dim3(256), 4 * XW_TILE, st, a);
 }
 
 // ---- not built yet: the engine routes these stages to the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*)
