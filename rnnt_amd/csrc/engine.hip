@@ -283,7 +283,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.denom_s = denom_s; h.lpb_s = lpb_s; h.lpe_s = lpe_s; h.D = L.D;
         h.slab_enc = g.slab_enc; h.slab_pred = g.slab_pred; h.slab_w = g.slab_w; h.slab_b = g.slab_b;
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
-        h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags;
+        h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags; h.n_ublk16 = (U1 + 15) / 16;
         h.dw_tab = (long *)(ws + L.counters + 1024);
         h.counter = (unsigned *)(ws + L.counters + 512); h.n_cu = device_cus();
         const bool f32_dh = (xflags & RNNT_VARIANT_X3_FP32_DH) != 0 || !x3_dhidden_ok(U1, H, V);

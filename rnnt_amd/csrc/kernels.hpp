@@ -140,6 +140,7 @@ struct X3Args {
     long rows_pad;       // K extent of the dW GEMM (multiple of 32)
     int B, T, U1, H, V, blank;
     int n_ublk, n_split;
+    int n_ublk16;        // u blocks of k_dhidden_x3 (16 wide)
     int flags;
     long *dw_tab;        // 2B+2 longs: live-row table of k_dw_x3 (k_dw_table, 32-cell granules)
     unsigned *counter;   // zeroable word: tile counter of the persistent forward

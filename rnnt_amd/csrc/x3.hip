@@ -458,9 +458,380 @@ void launch_dw_x3(const X3Args &a, hipStream_t st)
 
 // ---- not built yet: the engine routes these stages to the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*)
 bool x3_fwd_ok(int, int, int) { return false; }
-bool x3_dhidden_ok(int, int, int) { return false; }
 size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)3 * ((V + 511) / 512 * 512) * H * 2; }
-size_t x3_wpack_dh_bytes(int H, int V) { return (size_t)3 * ((H + 511) / 512 * 512) * V * 2; }
-void launch_x3_pack_w(const X3Args &, hipStream_t) {}
 void launch_joint_fwd_x3(const X3Args &, hipStream_t) {}
-void launch_dhidden_x3(const X3Args &, hipStream_t) {}
+
+// ---------------------------------------------------------------------------------------
+// W for the dHidden product, fragment order, three planes:
+//   [hp (512-column pass)][c (16-deep k-step = 16 vocabulary rows)][plane][tile(16)][lane] x 8 bf16,
+//   element j = piece_plane(W[v = 16c + 8*(lane>>5) + j][h = 512hp + 128*(tile>>2) + 4*(lane&31) + (tile&3)])
+// (columns interleaved by 4: a lane's 4 tiles of a 128-column group are 4 adjacent columns -> 16-byte
+// epilogue accesses).  One k-step = 3 x 16 KiB, staged by one linear LDS-DMA copy.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_x3_pack_w_dh(const float *__restrict__ W, u32x4 *__restrict__ out, int H, int V, long n)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (hp, c, tile, lane): one thread writes the 3 planes
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 15;
+    const int VC = V / 16;
+    const int c = (int)((idx >> 10) % VC), hp = (int)((idx >> 10) / VC);
+    const int h = 512 * hp + 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
+    const int v0 = 16 * c + 8 * (lane >> 5);
+    u32x4 ph = {0u, 0u, 0u, 0u}, pm = ph, pl = ph;
+    if (h < H) {
+        const float *w = W + (long)v0 * H + h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const X3Pieces q = x3_split2(w[(long)(2 * j) * H], w[(long)(2 * j + 1) * H]);
+            ph[j] = q.h; pm[j] = q.m; pl[j] = q.l;
+        }
+    }
+    u32x4 *o = out + ((long)hp * VC + c) * 3072 + tile * 64 + lane;
+    o[0] = ph; o[1024] = pm; o[2048] = pl;
+}
+size_t x3_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V / 16) * 3 * 16 * 64 * 16; }
+
+// ---------------------------------------------------------------------------------------
+// k_dhidden_x3: G from the fp32 logits (exp2 + the two occupancy corrections, as the fp32 route), split
+// into its three planes, stored in place (hi | mid over each 32-wide chunk of the logits row, lo beside)
+// and multiplied: dHidden = G . W over 512 columns of H per launch; epilogue as the fp32 kernel:
+// x (1 - hidden^2), sum over u -> dEnc slab, sum over t -> dPred slab.  Tile = 8 t x 16 u cells.
+// 4 waves = 2 (M) x 2 (N), wave tile 64 cells x 256 columns = 16 accumulator tiles (256 registers).
+//  * production: wave w turns M tile w (32 cells) into G: lane (cell i = l&31, half) owns the 8 vocabulary
+//    entries 16c + 8*half .. +7 of its cell per k-step — exactly its slot of the MFMA A fragment — and drops
+//    16 bytes per plane into the LDS exchange [2 slots][M tile][plane][lane]; logits requested 4 k-steps ahead
+//    (register ring), G stored from the producer's registers (3 x 16 B per lane and k-step);
+//  * W: one linear LDS-DMA copy of 48 KiB per k-step into a 2-slot ring (12 DMAs per wave);
+//  * per k-step ONE barrier publishes W slot c and exchange slot c; behind it the wave first issues its
+//    fragment reads, then produces G of step c+1 while they land (the production fills the LDS latency),
+//    then runs 6 products x 16 MFMAs with the DMAs of W step c+1 threaded through the first ones (their
+//    target slot was read during step c-1: every wave is past it).
+// Product order keeps the 8 B fragments of one W plane live at a time: (ah,am,al).bh, (ah,am).bm, ah.bl.
+// FIRST = false (H > 512: columns 512.., one launch per further 512): G's planes are read back from
+// memory into the exchange instead of being produced; nothing is stored but the slabs.
+// grid (n_ublk, ceil(T/8), B).  Requires V % 128 == 0, H % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define XG_BT 8
+#define XG_BU 16
+#define XG_WSLOT 49152   // one k-step of W: 3 planes x 16 tiles x 1 KiB
+#define XG_XSLOT 12288   // one k-step of G fragments: 4 M tiles x 3 planes x 1 KiB
+template <bool FIRST>
+__global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
+{
+    // [0, 96 KiB): W ring, 2 slots;  [96, 120 KiB): G exchange, 2 slots.  The epilogue reuses the W ring.
+    extern __shared__ __attribute__((aligned(1024))) char s_dh[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
+    const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
+    int Tb, Ub;
+    len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub);
+    const int t0 = tt * XG_BT, u0 = ub * XG_BU;
+    const int VC = V / 16;
+
+    // ---- producer role: M tile `wave`, row i = cell (pt, pu)
+    const int prow = wave * 32 + i;
+    const int pt = t0 + (prow >> 4), pu = u0 + (prow & 15);
+    const bool pexists = pt < T && pu < U1;
+    const long zrow = (long)a.B * T * U1;  // first zero padding row
+    const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : zrow;
+
+    // workgroup-uniform: no products past the utterance's length or in a u block past U_b (no lattice cell; the
+    // reductions skip its slabs), but k_dw_x3 must find zeros in these rows (all three planes)
+    if (t0 >= Tb || u0 > Ub) {
+        if (FIRST && pexists) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            u32x4 *g = (u32x4 *)(a.logits + pcell * V) + half;
+            u32x4 *gl = (u32x4 *)(a.g_lo + pcell * V) + half;
+            for (int c = 0; c < VC; ++c) {  // this lane's 16 B of each plane per k-step (layout below)
+                g[8 * (c >> 1) + 2 * (c & 1)] = z;
+                g[8 * (c >> 1) + 4 + 2 * (c & 1)] = z;
+                gl[2 * c] = z;
+            }
+        }
+        return;
+    }
+
+    CellCoef cf = a.coef[pexists ? pcell : 0];
+    const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
+    if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
+    // The producer's memory, per k-step c (16 vocabulary entries, this lane: 8 of them, v = 16c + 8half + j):
+    //   logits (fp32): 32 bytes at row + 64c + 32half               (f32x4 index 4c + 2half, +1)
+    //   G hi: 16 bytes at row + 128(c>>1) + 32(c&1) + 16half        (u32x4 index 8(c>>1) + 2(c&1) + half)
+    //   G mid: the same + 64 bytes;  G lo: 16 bytes at lo row + 32c + 16half
+    // rows outside the lattice read the zero padding row (finite) with c1 = -inf -> G = 0; FIRST = false: every
+    // existing row holds its G planes already
+    const float *xsrc = a.logits + ((FIRST ? live : pexists) ? pcell : zrow) * V;
+    u32x4 *gdst = (u32x4 *)(a.logits + pcell * V) + half;
+    u32x4 *ldst = (u32x4 *)(a.g_lo + pcell * V) + half;
+    const u32x4 *lsrc = (const u32x4 *)(a.g_lo + (pexists ? pcell : zrow) * V) + half;
+    const int blank = a.blank;
+
+    f32x16 acc[2][8];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+
+    const int lds0 = (int)(size_t)(lds_vptr)s_dh;
+    const int xw = lds0 + 2 * XG_WSLOT + wave * 3072 + 16 * lane;       // exchange write: [slot][M tile wave][plane][lane]
+    const int xa = lds0 + 2 * XG_WSLOT + (2 * wm) * 3072 + 16 * lane;   // exchange read: M tiles 2wm, 2wm+1
+    const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                  // W read: tiles 8wn .. 8wn+7 of each plane
+    // W DMA: wave w copies pieces 12w .. 12w+11 of the k-step's 48 (piece = 1 KiB = one (plane, tile))
+    const u32x4 *wsrc = (const u32x4 *)a.wpack_dh + (long)hp * VC * 3072 + (wave * 12) * 64 + lane;
+
+    struct Raw { f32x4 x0, x1; u32x4 l; };  // FIRST: 8 fp32 logits; else: hi | mid (as x0, x1 bits) and lo planes
+    auto xload = [&](Raw &r, int c) {
+        const int cc = c < VC ? c : VC - 1;
+        if (FIRST) {
+            const f32x4 *p = (const f32x4 *)xsrc + 4 * cc + 2 * half;
+            r.x0 = p[0]; r.x1 = p[1];
+        } else {
+            const u32x4 *p = (const u32x4 *)xsrc + 8 * (cc >> 1) + 2 * (cc & 1) + half;
+            r.x0 = __builtin_bit_cast(f32x4, p[0]); r.x1 = __builtin_bit_cast(f32x4, p[4]);
+            r.l = lsrc[2 * cc];
+        }
+    };
+    // G of k-step c from the raw values -> exchange slot (c & 1), and (FIRST) to memory
+    auto produce = [&](const Raw &r, int c) {
+        u32x4 ph, pm, pl;
+        if (FIRST) {
+            f32x4 g0, g1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g0[e] = __builtin_amdgcn_exp2f(fmaf(r.x0[e], RNNT_LOG2E, cf.c1));
+                g1[e] = __builtin_amdgcn_exp2f(fmaf(r.x1[e], RNNT_LOG2E, cf.c1));
+            }
+            const int vb = 16 * c + 8 * half;
+            const unsigned dy = (unsigned)(cf.y - vb);
+            if (__any(dy < 8u)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g0[e] = (dy == (unsigned)e) ? g0[e] - cf.se : g0[e];
+                    g1[e] = (dy == (unsigned)(e + 4)) ? g1[e] - cf.se : g1[e];
+                }
+            }
+            if ((unsigned)(blank - 16 * c) < 16u) {  // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g0[e] = (vb + e == blank) ? g0[e] - cf.sb : g0[e];
+                    g1[e] = (vb + e + 4 == blank) ? g1[e] - cf.sb : g1[e];
+                }
+            }
+            X3_SPLIT4(g0, ph, pm, pl, 0);
+            X3_SPLIT4(g1, ph, pm, pl, 2);
+        } else {
+            ph = __builtin_bit_cast(u32x4, r.x0); pm = __builtin_bit_cast(u32x4, r.x1); pl = r.l;
+        }
+        const int dst = xw + (c & 1) * XG_XSLOT;
+        asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(ph) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(pm) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(pl) : "memory");
+        if (FIRST && pexists && !RNNT_XP(a.flags, 256)) {
+            gdst[8 * (c >> 1) + 2 * (c & 1)] = ph;
+            gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = pm;
+            ldst[2 * c] = pl;
+        }
+    };
+    auto wdma = [&](int c, int n) {  // piece n (0..11) of this wave's share of W k-step c -> ring slot c & 1
+        const int cc = c < VC ? c : VC - 1;
+        if (RNNT_XP(a.flags, 8192)) return;
+        __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cc * 3072 + n * 64),
+                                         (lds_vptr)(s_dh + (c & 1) * XG_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
+    };
+
+    Raw xr[4];  // raw ring (slot = k-step & 3), 4 k-steps ahead of production
+    xload(xr[0], 0); xload(xr[1], 1); xload(xr[2], 2); xload(xr[3], 3);
+#pragma unroll
+    for (int n = 0; n < 12; ++n) wdma(0, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the in-place stores of k-step 0 overwrite logits of k-step 1
+    produce(xr[0], 0);
+    xload(xr[0], 4);
+
+    for (int c0 = 0; c0 < VC; c0 += 4) {  // VC % 4 == 0 (V % 128 == 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            // W k-step c landed (this wave's share), G fragments of step c written: publish both; every wave is
+            // past its reads of step c-1 (W slot and exchange slot of c+1)
+            // (vmcnt retires in order and the DMAs are the youngest operations of the previous step: 0.  It also
+            // orders the in-place G stores behind every earlier logits load of the same bytes.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x3_lds_barrier();
+            const int ws = wb + (j & 1) * XG_WSLOT, xs = xa + (j & 1) * XG_XSLOT;
+            u32x4 af[2][3], bf[8], bn[8];
+            // fragment reads: A (6) and the hi plane of W (8)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 3072 + p * 1024));
+            if (!RNNT_XP(a.flags, 4096)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
+            }
+            // while they land: G of k-step c+1 into the other exchange slot, and its logits ring refill
+            if (c + 1 < VC) produce(xr[(j + 1) & 3], c + 1);  // workgroup-uniform
+            xload(xr[(j + 1) & 3], c + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(3)"  // the three exchange writes of produce() may still fly
+                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
+                           "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
+                         :: "memory");
+            // one product block: 16 MFMAs = (2 M tiles) x (8 column tiles) for A plane PA against the B plane held
+            // in `bcur`; optionally the next B plane's 8 fragment reads (NB: plane index, -1 none) and W DMA pieces
+            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c) {
+                constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!RNNT_XP(a.flags, 1024)) {
+                        acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
+                        acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
+                    }
+                    if (NB >= 0 && !RNNT_XP(a.flags, 4096))
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
+                    if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+#define XG_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
+            block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{});   // ah.bh   + DMA pieces 0-3
+            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<4>{});    // am.bh   + reads of W mid, DMA pieces 4-7
+            XG_WAIT8(bn);
+            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{});   // al.bh   + DMA pieces 8-11
+            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{});   // ah.bm   + reads of W lo (into the hi registers)
+            XG_WAIT8(bf);
+            block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{});  // am.bm
+            block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued ring loads / DMAs
+    __syncthreads();
+
+    // ---- epilogue.  Accumulator register rr = 8rh + r7 of M tile (2wm + mt), column tile q: row (rr&3) + 8(rr>>2) +
+    // 4half of its 32 = t row 2(2wm+mt) + rh, u slot 8(r7>>2) + (r7&3) + 4half; column 512hp + 256wn + 128(q>>2) +
+    // 4i + (q&3).  hidden = hi + mid + lo of the planes (exact), through a raw buffer over the tile's rows.
+    if (RNNT_XP(a.flags, 16384)) return;
+    float (*s_red)[64][65] = (float (*)[64][65])s_dh;  // [wn][lane][8 u slots x 8 columns]
+    const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+    const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
+    const bool colok[2] = {colg[0] < H, colg[1] < H};
+    const long cell0 = ((long)b * T + t0) * U1 + u0;
+    const long rows_left = a.rows_alloc - cell0;
+    const long span0 = (long)(XG_BT - 1) * U1 + XG_BU < rows_left ? (long)(XG_BT - 1) * U1 + XG_BU : rows_left;
+    const long rows_utt = (long)(T - t0) * U1 - u0;  // never into the next utterance's rows
+    const long span = span0 < rows_utt ? span0 : rows_utt;
+    __amdgpu_buffer_rsrc_t hrs[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        hrs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hidden + p * a.plane_stride + cell0 * H), 0, (int)(span * H * 2), 0x00020000);
+    const unsigned hvoff[2] = {colok[0] ? (unsigned)(((4 * half) * H + colg[0]) * 2) : 0xfffffff0u,
+                               colok[1] ? (unsigned)(((4 * half) * H + colg[1]) * 2) : 0xfffffff0u};
+    float psum[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            const int tl = 2 * (2 * wm + mt) + rh;  // t row inside the tile
+            float esum[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] = 0.f;
+            u32x2 hq[8][2][3];
+#pragma unroll
+            for (int r7 = 0; r7 < 8; ++r7) {
+                const unsigned soff = (unsigned)((tl * U1 + 8 * (r7 >> 2) + (r7 & 3)) * H) * 2u;
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        hq[r7][g][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(hrs[p], hvoff[g], soff, 0));
+            }
+#pragma unroll
+            for (int r7 = 0; r7 < 8; ++r7)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float hv[4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        hv[2 * e] = (x3_lo(hq[r7][g][0][e]) + x3_lo(hq[r7][g][1][e])) + x3_lo(hq[r7][g][2][e]);
+                        hv[2 * e + 1] = (x3_hi(hq[r7][g][0][e]) + x3_hi(hq[r7][g][1][e])) + x3_hi(hq[r7][g][2][e]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d = acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - hv[q] * hv[q]);
+                        esum[g * 4 + q] += d;
+                        psum[r7][g * 4 + q] += d;
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
+            const int t = t0 + tl;
+            if (half == 0 && t < Tb) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        const f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
+                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
+                    }
+            }
+        }
+    if (wm == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_red[wn][lane][k * 8 + q] = psum[k][q];
+    }
+    __syncthreads();
+    if (wm == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = u0 + 8 * (k >> 2) + (k & 3) + 4 * half;
+            if (u < U1) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = psum[k][g * 4 + q] + s_red[wn][lane][k * 8 + g * 4 + q];
+                        *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + colg[g]) = o;
+                    }
+            }
+        }
+    }
+}
+
+bool x3_dhidden_ok(int U1, int H, int V)
+{
+    // raw buffers over one tile's hidden rows (32-bit byte offsets), W pack addressing
+    return (long)((XG_BT - 1) * (long)U1 + XG_BU) * H * 2 < 0x7fffffffL && V % 128 == 0 && H % 128 == 0;
+}
+
+void launch_x3_pack_w(const X3Args &a, hipStream_t st)
+{
+    const long nd = (long)((a.H + 511) / 512) * (a.V / 16) * 16 * 64;
+    hipLaunchKernelGGL(k_x3_pack_w_dh, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a.W, (u32x4 *)a.wpack_dh, a.H, a.V, nd);
+}
+
+void launch_dhidden_x3(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = 2 * XG_WSLOT + 2 * XG_XSLOT;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    dim3 grid(a.n_ublk16, (a.T + XG_BT - 1) / XG_BT, a.B);
+    hipLaunchKernelGGL(k_dhidden_x3<true>, grid, dim3(256), lds, st, a, 0);
+    for (int hp = 1; hp * 512 < a.H; ++hp) hipLaunchKernelGGL(k_dhidden_x3<false>, grid, dim3(256), lds, st, a, hp);
+}
