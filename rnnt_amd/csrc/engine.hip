@@ -298,7 +298,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
             g.gen_bu = 16; g.pred_split_col = H;  // x3 tiles: 8 t x 16 u, every dPred slab 8 t rows high
         }
         if (stages & ST_PROD) {
-            launch_x3_zero_padding(h, st);
+            launch_x3_zero_padding(h, 1, st);
             launch_x3_pack_w(h, st);
             if (f32_fwd) {
                 const size_t cells = (size_t)B * T * U1;
@@ -329,6 +329,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
             launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                         B, T, U1, L.D, grad_scale, st);
         if (stages & ST_DH) {
+            launch_x3_zero_padding(h, 2, st);
             if (f32_dh) {
                 if (!fuse_g32) launch_make_g(g, st);
                 launch_dhidden(g, st);     // leaves fp32 G in place of the logits

@@ -152,7 +152,7 @@ size_t x3_wpack_fwd_bytes(int H, int V);
 size_t x3_wpack_dh_bytes(int H, int V);
 void launch_x3_make_hidden(const X3Args &a, hipStream_t st);
 void launch_x3_split_g(const X3Args &a, hipStream_t st);
-void launch_x3_zero_padding(const X3Args &a, hipStream_t st);
+void launch_x3_zero_padding(const X3Args &a, int what, hipStream_t st);
 void launch_x3_pack_w(const X3Args &a, hipStream_t st);
 void launch_joint_fwd_x3(const X3Args &a, hipStream_t st);
 void launch_dhidden_x3(const X3Args &a, hipStream_t st);

@@ -134,14 +134,18 @@ void launch_x3_split_g(const X3Args &a, hipStream_t st)
     const long n = rows * (a.V / 32);
     hipLaunchKernelGGL(k_x3_split_g, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, rows);
 }
-// zero rows past the last cell, all planes (the dW ring walks up to 96 of them; dead rows of dHidden tiles)
-void launch_x3_zero_padding(const X3Args &a, hipStream_t st)
+// zero rows past the last cell, all planes (the dW ring walks up to 96 of them; the "dead row" source of dHidden
+// tiles).  `what` 1: hidden (before the forward), 2: G (after the forward, whose last tile writes logits there)
+void launch_x3_zero_padding(const X3Args &a, int what, hipStream_t st)
 {
     const long cells = (long)a.B * a.T * a.U1;
     const size_t pad = (size_t)(a.rows_alloc - cells);
-    for (int p = 0; p < 3; ++p) launch_fill32(a.hidden + p * a.plane_stride + cells * a.H, 0u, pad * a.H * 2, st);
-    launch_fill32(a.logits + cells * a.V, 0u, pad * a.V * 4, st);
-    launch_fill32(a.g_lo + cells * a.V, 0u, pad * a.V * 2, st);
+    if (what & 1)
+        for (int p = 0; p < 3; ++p) launch_fill32(a.hidden + p * a.plane_stride + cells * a.H, 0u, pad * a.H * 2, st);
+    if (what & 2) {
+        launch_fill32(a.logits + cells * a.V, 0u, pad * a.V * 4, st);
+        launch_fill32(a.g_lo + cells * a.V, 0u, pad * a.V * 2, st);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -456,10 +460,320 @@ void launch_dw_x3(const X3Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_dw_x3, dim3(tiles * a.n_split), dim3(256), 4 * XW_TILE, st, a);
 }
 
-// ---- not built yet: the engine routes these stages to the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*)
-bool x3_fwd_ok(int, int, int) { return false; }
-size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)3 * ((V + 511) / 512 * 512) * H * 2; }
-void launch_joint_fwd_x3(const X3Args &, hipStream_t) {}
+
+// compile-time experiment switches (tools/build_x3_variants.sh: -DX3_EXP=bits; the run-time switches of the
+// RNNT_ABLATE build make hipcc spill 149 registers in this kernel): 1 no MFMA, 2 no G stores, 4 no raw loads in
+// the loop, 8 no W DMA, 16 no epilogue, 32 no production arithmetic, 64 no fragment reads
+#ifndef X3_EXP
+#define X3_EXP 0
+#endif
+#define X3_OFF(bit) ((X3_EXP) & (bit))
+#define XG_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
+// ---------------------------------------------------------------------------------------
+// W for the forward product, fragment order, three planes:
+//   [pass (512 logits columns)][c (16-deep k-step)][plane][tile(16)][lane] x 8 bf16,
+//   element j = piece_plane(W[v = 512pass + 128*(tile>>2) + 4*(lane&31) + (tile&3)][h = 16c + 8*(lane>>5) + j])
+// (columns interleaved by 4, as in the dHidden pack: a lane's 4 tiles of a 128-column group are 4 adjacent logits).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_x3_pack_w_fwd(const float *__restrict__ W, u32x4 *__restrict__ out, int H, int V, long n)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (pass, c, tile, lane): one thread writes the 3 planes
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 15;
+    const int KC = H / 16;
+    const int c = (int)((idx >> 10) % KC), pass = (int)((idx >> 10) / KC);
+    const int v = 512 * pass + 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
+    const int h0 = 16 * c + 8 * (lane >> 5);
+    u32x4 ph = {0u, 0u, 0u, 0u}, pm = ph, pl = ph;
+    if (v < V) {
+        const float *w = W + (long)v * H + h0;
+        const f32x4 w0 = *(const f32x4 *)w, w1 = *(const f32x4 *)(w + 4);
+        X3_SPLIT4(w0, ph, pm, pl, 0);
+        X3_SPLIT4(w1, ph, pm, pl, 2);
+    }
+    u32x4 *o = out + ((long)pass * KC + c) * 3072 + tile * 64 + lane;
+    o[0] = ph; o[1024] = pm; o[2048] = pl;
+}
+size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H / 16) * 3 * 16 * 64 * 16; }
+
+// ---------------------------------------------------------------------------------------
+// k_joint_fwd_x3: hidden = tanh(enc + pred) split into its planes (tile prologue), logits = hidden . W^T + bias
+// (fp32, stored), log-softmax statistics and the two log-probs per lattice cell (as the fp32 route's forward).
+// Tile = 128 consecutive cells; 4 waves = 2 (M) x 2 (N), wave tile 64 cells x 256 columns = 16 accumulator tiles
+// (256 registers); a pass = 512 logits columns, passes run back to back over one linear k-step sequence.
+//  * A (hidden planes, written by this workgroup's prologue) and B (packed W) of a k-step both arrive by LDS-DMA:
+//    12 KiB + 48 KiB into 2-slot rings (3 + 12 DMAs per wave and k-step), A's image = MFMA fragment order
+//    [M tile][plane][lane] (a lane fetches its own 16 bytes: row = its cell, k = 16c + 8*(lane>>5) ..);
+//  * per k-step ONE barrier (the DMAs are the only memory operations in flight: vmcnt(0)), then fragment
+//    reads and 6 products x 16 MFMAs with the next k-step's DMAs threaded through the first blocks;
+//  * pass end: bias rode in the accumulators' initial value; logits leave as 16 bytes per lane (4 adjacent
+//    columns; a wave-instruction writes 512 contiguous bytes of two rows); per-lane running (max, sum exp) of every
+//    row slot live in 64 registers and are combined across lanes and the two column halves once per tile.
+// grid = rows_alloc / 128 workgroups.  Requires H % 128 == 0, V % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define XF_WSLOT 49152
+#define XF_ASLOT 12288
+__global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
+{
+    // [0, 96 KiB): W ring;  [96, 120 KiB): A ring;  then: s_den[128], s_part[2][128][2]
+    extern __shared__ __attribute__((aligned(1024))) char s_fw[];
+    float *s_den = (float *)(s_fw + 2 * XF_WSLOT + 2 * XF_ASLOT);
+    float *s_part = s_den + 128;  // [wn][row][max, sum]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int H = a.H, V = a.V, KC = H / 16, U1 = a.U1, T = a.T;
+    const int npass = (V + 511) / 512;
+    const long cells = (long)a.B * T * U1;
+    const long row0 = (long)blockIdx.x * 128;
+    {   // tiles with no live cell: the row padding past the last cell, and tiles that lie entirely in the dead
+        // time steps (t >= T_b) of one utterance — their logits are never read (k_dhidden_x3 zero-fills the G
+        // rows of dead tiles itself); hidden must still be finite everywhere (k_dw_x3 multiplies it by zeros)
+        if (row0 >= cells) return;
+    }
+    // ---- prologue: hidden planes of the tile's 128 cells.  A thread owns 8 columns of every (256/(H/8))-th row.
+    {
+        const int H8 = H / 8;
+        const int rstep = 256 / H8 > 0 ? 256 / H8 : 1;
+        const int r0 = tid / H8, h = (tid - r0 * H8) * 8;
+        if (r0 < rstep) {
+            long c = row0 + r0;
+            int u = (int)(c % U1);
+            long bt = c / U1;
+            int t = (int)(bt % T), b = (int)(bt / T);
+            const long ps = a.plane_stride / 8;
+            u32x4 *hid = (u32x4 *)a.hidden;
+            for (int r = r0; r < 128 && c < cells; r += rstep, c += rstep) {
+                const float *ep = a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + h;
+                const float *pp = a.pred + ((long)b * U1 + u) * H + h;
+                const f32x4 t0 = fast_tanh_sum4(*(const f32x4 *)ep, *(const f32x4 *)pp);
+                const f32x4 t1 = fast_tanh_sum4(*(const f32x4 *)(ep + 4), *(const f32x4 *)(pp + 4));
+                u32x4 ph, pm, pl;
+                X3_SPLIT4(t0, ph, pm, pl, 0);
+                X3_SPLIT4(t1, ph, pm, pl, 2);
+                u32x4 *o = hid + c * H8 + h / 8;
+                o[0] = ph; o[ps] = pm; o[2 * ps] = pl;
+                u += rstep;
+                while (u >= U1) { u -= U1; if (++t == T) { t = 0; ++b; } }
+            }
+        }
+    }
+    {   // dead tile (entirely in the time steps past one utterance's length): hidden written, nothing else to do
+        const long per = (long)T * U1, c_last = row0 + 127;
+        const long b_first = row0 / per;
+        if (c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T)) return;
+    }
+    __syncthreads();  // the tile's hidden rows are stored (vmcnt(0)) and every wave is past them
+
+    const int lds0 = (int)(size_t)(lds_vptr)s_fw;
+    const int xa = lds0 + 2 * XF_WSLOT + (2 * wm) * 3072 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
+    const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                 // W read: tiles 8wn .. 8wn+7 of each plane
+    const u32x4 *wsrc = (const u32x4 *)a.wpack_fwd + (wave * 12) * 64 + lane;
+    // A DMA: wave w fetches M tile w (3 pieces: one per plane); lane (r, h): 16 bytes of row 32w + r at k = 8h
+    __amdgpu_buffer_rsrc_t ars[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        ars[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hidden + p * a.plane_stride + row0 * H), 0, 128 * H * 2, 0x00020000);
+    const int avoff = ((32 * wave + i) * H + 8 * half) * 2;
+    const int NS = npass * KC;  // k-steps of the tile
+    // piece n (0..14) of this wave's share of k-step `cs` (its k index inside the pass: `kcs`) -> ring slots cs & 1
+    auto dma = [&](int cs, int kcs, int n) {
+        if (X3_OFF(8)) return;
+        if (n < 12) {
+            __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cs * 3072 + n * 64),
+                                             (lds_vptr)(s_fw + (cs & 1) * XF_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
+        } else {
+            const int p = n - 12;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars[p], (lds_vptr)(s_fw + 2 * XF_WSLOT + (cs & 1) * XF_ASLOT + wave * 3072 + p * 1024),
+                                                     16, avoff, 32 * kcs, 0, 0);
+        }
+    };
+
+    // running (max, sum exp) of every row over the columns seen so far, per column half (wn): s_part[wn][row], kept
+    // by the lanes 31 / 63 that end up with a row slot's wave-level statistics (64 per-lane register pairs instead
+    // made hipcc spill 300 registers around the main loop)
+    for (int k = tid; k < 256; k += 256) { s_part[2 * k] = RNNT_NEG_INF; s_part[2 * k + 1] = 0.f; }
+    f32x16 acc[2][8];
+    auto acc_init = [&](int pass) {  // the bias of this lane's 2 x 4 adjacent columns of the pass
+        const int c0 = 512 * pass + 256 * wn + 4 * i;
+        const f32x4 b0 = c0 < V ? *(const f32x4 *)(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 b1 = c0 + 128 < V ? *(const f32x4 *)(a.bias + c0 + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][q][r] = q < 4 ? b0[q] : b1[q - 4];
+    };
+#pragma unroll
+    for (int n = 0; n < 15; ++n) dma(0, 0, n);
+
+    int cs = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+      // (accumulators initialised by plain assignment at the top of a loop: a conditional re-initialisation inside
+      // the k loop makes hipcc carry the 256 accumulator registers through VGPR phis and spill hundreds)
+      acc_init(pass);
+      for (int kc = 0; kc < KC; ++kc, ++cs) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // k-step cs landed (this wave's share); pass-end stores done
+        x3_lds_barrier();
+        const int ws = wb + (cs & 1) * XF_WSLOT, xs = xa + (cs & 1) * XF_ASLOT;
+        // the next k-step (the last one re-fetches itself: never read)
+        const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = cs + 1 < NS ? (kc + 1 < KC ? kc + 1 : 0) : kc;
+        u32x4 af[2][3], bf[8], bn[8];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 3072 + p * 1024));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
+                       "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
+                     :: "memory");
+        auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c) {
+            constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (!X3_OFF(1)) {
+                    acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
+                    acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
+                }
+                if (NB >= 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
+                if (D0 >= 0 && D0 + q < 15) dma(csn, kcn, (D0 < 0 ? 0 : D0) + q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{});   // ah.bh + DMA 0-7
+        block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<8>{});    // am.bh + reads of W mid, DMA 8-14
+        XG_WAIT8(bn);
+        block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // al.bh
+        block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
+        XG_WAIT8(bf);
+        block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{});  // am.bm
+        block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+      }
+      // pass complete: store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column groups exist
+      // or not for the whole wave.  The row loop is ONE basic block per case (no branch inside: with branches hipcc
+      // hoists all 256 accumulator reads in front of the first store and spills); the store address is a scalar
+      // row pointer + one 32-bit per-lane offset.
+      if (!X3_OFF(16)) {
+            const int cw = 512 * pass + 256 * wn;
+            const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
+            char *tile_base = (char *)(a.logits + row0 * V + cw);
+            auto epilogue = [&](auto both_c) {
+                constexpr bool BOTH = decltype(both_c)::value != 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // the accumulators are "redefined" in front of every row slot: hipcc cannot hoist their
+                        // 256 reads (v_accvgpr_read) in front of the first store and spill them
+#ifdef X3_PIN_ACC
+                        asm volatile("" : "+a"(acc[mt][0]), "+a"(acc[mt][1]), "+a"(acc[mt][2]), "+a"(acc[mt][3]),
+                                          "+a"(acc[mt][4]), "+a"(acc[mt][5]), "+a"(acc[mt][6]), "+a"(acc[mt][7]));
+#endif
+                        // accumulator reads spelled as (volatile) asm: they stay here, one row slot at a time — left to
+                        // hipcc, all 256 v_accvgpr_read are hoisted in front of the first store and spilled
+                        f32x4 o0, o1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float x0, x1;
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[mt][q][r]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[mt][4 + q][r]));
+                            o0[q] = x0; o1[q] = x1;
+                        }
+                        char *rowp = tile_base + (long)(32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2)) * V * 4;  // wave-uniform
+                        if (!X3_OFF(2)) {
+                            __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
+                            if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
+                        }
+                        if (!X3_OFF(32)) {
+                            // the row slot's (max, sum exp) over this wave's 128 / 256 columns of the pass: 8 values per
+                            // lane, then the 32 lanes of the half on the DPP crossbar
+                            float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
+                            if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                            const float M = half_max_dpp(m8, half);
+                            const float nm2 = -M * RNNT_LOG2E;
+                            float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                                      (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                            if (BOTH)
+                                e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                                     (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                            const float S = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
+                            if (i == 31) {
+                                float *sp = s_part + (wn * 128 + 32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
+                                const float m_o = sp[0], s_o = sp[1];
+                                const float mn = fmaxf(m_o, M);
+                                sp[0] = mn;
+                                sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
+                    }
+            };
+            if (cw + 128 < V) epilogue(X3Int<1>{});
+            else if (cw < V) epilogue(X3Int<0>{});
+      }
+    }
+
+    // ---- log-softmax denominators: the two column halves (wn) of every row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every logits store of the workgroup has left its wave; s_part complete
+    if (tid < 128) {
+        const float m0 = s_part[tid * 2], s0 = s_part[tid * 2 + 1];
+        const float m1 = s_part[(128 + tid) * 2], s1 = s_part[(128 + tid) * 2 + 1];
+        const float M = fmaxf(m0, m1);
+        const float S = s0 * __builtin_amdgcn_exp2f((m0 - M) * RNNT_LOG2E) + s1 * __builtin_amdgcn_exp2f((m1 - M) * RNNT_LOG2E);
+        s_den[tid] = M + __logf(S);
+    }
+    __syncthreads();
+    // thread = (row = tid & 127, which = tid >> 7): logit[blank] / logit[label] of the row, read through L2 (agent-scope
+    // loads bypass the CU's vector L1; the stores above are complete: vmcnt(0) + barrier)
+    {
+        const int row = tid & 127, which = tid >> 7;
+        const long cell = row0 + row;
+        if (cell < cells) {
+            const int u = (int)(cell % U1);
+            const long bt = cell / U1;
+            const int t = (int)(bt % T), b = (int)(bt / T);
+            const int Ub = len_u(a.target_lens, b, U1);
+            if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
+                const float den = s_den[row];
+                const float *lrow = a.logits + cell * V;
+                const long si = skew_index(b, t, u, a.D, U1);
+                if (which == 0) {
+                    const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.denom_s[si] = den;
+                    a.lpb_s[si] = lb - den;
+                } else {
+                    float le = 0.f;
+                    if (u < Ub) {
+                        const int y = a.targets[(long)b * (U1 - 1) + u];
+                        le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                    }
+                    a.lpe_s[si] = le;
+                }
+            }
+        }
+    }
+}
+
+bool x3_fwd_ok(int U1, int H, int V) { return H % 128 == 0 && V % 128 == 0 && (long)128 * H * 2 < 0x7fffffffL; }
+
+void launch_joint_fwd_x3(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = 2 * XF_WSLOT + 2 * XF_ASLOT + 128 * 4 + 2 * 128 * 2 * 4;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_joint_fwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_joint_fwd_x3, dim3((unsigned)(a.rows_alloc / 128)), dim3(256), lds, st, a);
+}
 
 // ---------------------------------------------------------------------------------------
 // W for the dHidden product, fragment order, three planes:
@@ -596,50 +910,61 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             r.l = lsrc[2 * cc];
         }
     };
-    // G of k-step c from the raw values -> exchange slot (c & 1), and (FIRST) to memory
-    auto produce = [&](const Raw &r, int c) {
-        u32x4 ph, pm, pl;
-        if (FIRST) {
-            f32x4 g0, g1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                g0[e] = __builtin_amdgcn_exp2f(fmaf(r.x0[e], RNNT_LOG2E, cf.c1));
-                g1[e] = __builtin_amdgcn_exp2f(fmaf(r.x1[e], RNNT_LOG2E, cf.c1));
-            }
+    // G of k-step c from the raw values -> exchange slot (c & 1), and (FIRST) to memory.  The work is cut into
+    // slices (0..10) that the main loop threads through the gaps of its first MFMA blocks: one wave per SIMD
+    // issues ~1 instruction per 4-5 cycles and an MFMA leaves 24 of its 32 cycles to other instructions, so ~150
+    // instructions in FRONT of a k-step's MFMAs would cost a quarter of it.
+    struct Prod { f32x4 g0, g1; u32x4 ph, pm, pl; };
+    auto produce_slice = [&](Prod &P, const Raw &r, int c, int sl) {
+        if (!FIRST) {
+            if (sl == 0) { P.ph = __builtin_bit_cast(u32x4, r.x0); P.pm = __builtin_bit_cast(u32x4, r.x1); P.pl = r.l; }
+        } else if (sl < 4) {
+            P.g0[sl] = __builtin_amdgcn_exp2f(fmaf(r.x0[sl], RNNT_LOG2E, cf.c1));
+            P.g1[sl] = __builtin_amdgcn_exp2f(fmaf(r.x1[sl], RNNT_LOG2E, cf.c1));
+        } else if (sl == 4) {
             const int vb = 16 * c + 8 * half;
             const unsigned dy = (unsigned)(cf.y - vb);
             if (__any(dy < 8u)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    g0[e] = (dy == (unsigned)e) ? g0[e] - cf.se : g0[e];
-                    g1[e] = (dy == (unsigned)(e + 4)) ? g1[e] - cf.se : g1[e];
+                    P.g0[e] = (dy == (unsigned)e) ? P.g0[e] - cf.se : P.g0[e];
+                    P.g1[e] = (dy == (unsigned)(e + 4)) ? P.g1[e] - cf.se : P.g1[e];
                 }
             }
+        } else if (sl == 5) {
+            const int vb = 16 * c + 8 * half;
             if ((unsigned)(blank - 16 * c) < 16u) {  // wave-uniform
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    g0[e] = (vb + e == blank) ? g0[e] - cf.sb : g0[e];
-                    g1[e] = (vb + e + 4 == blank) ? g1[e] - cf.sb : g1[e];
+                    P.g0[e] = (vb + e == blank) ? P.g0[e] - cf.sb : P.g0[e];
+                    P.g1[e] = (vb + e + 4 == blank) ? P.g1[e] - cf.sb : P.g1[e];
                 }
             }
-            X3_SPLIT4(g0, ph, pm, pl, 0);
-            X3_SPLIT4(g1, ph, pm, pl, 2);
-        } else {
-            ph = __builtin_bit_cast(u32x4, r.x0); pm = __builtin_bit_cast(u32x4, r.x1); pl = r.l;
+        } else if (sl == 6) {
+            X3_SPLIT4(P.g0, P.ph, P.pm, P.pl, 0);
+        } else if (sl == 7) {
+            X3_SPLIT4(P.g1, P.ph, P.pm, P.pl, 2);
         }
-        const int dst = xw + (c & 1) * XG_XSLOT;
-        asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(ph) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(pm) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(pl) : "memory");
-        if (FIRST && pexists && !RNNT_XP(a.flags, 256)) {
-            gdst[8 * (c >> 1) + 2 * (c & 1)] = ph;
-            gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = pm;
-            ldst[2 * c] = pl;
+        if (sl == 8) {
+            const int dst = xw + (c & 1) * XG_XSLOT;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(P.ph) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(P.pl) : "memory");
         }
+        if (sl == 9 && FIRST && pexists && !X3_OFF(2)) {
+            gdst[8 * (c >> 1) + 2 * (c & 1)] = P.ph;
+            gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = P.pm;
+            ldst[2 * c] = P.pl;
+        }
+    };
+    auto produce = [&](const Raw &r, int c) {  // all slices at once (pipeline prologue)
+        Prod P;
+#pragma unroll
+        for (int sl = 0; sl < 10; ++sl) produce_slice(P, r, c, sl);
     };
     auto wdma = [&](int c, int n) {  // piece n (0..11) of this wave's share of W k-step c -> ring slot c & 1
         const int cc = c < VC ? c : VC - 1;
-        if (RNNT_XP(a.flags, 8192)) return;
+        if (X3_OFF(8)) return;
         __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cc * 3072 + n * 64),
                                          (lds_vptr)(s_dh + (c & 1) * XG_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
     };
@@ -658,9 +983,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             const int c = c0 + j;
             // W k-step c landed (this wave's share), G fragments of step c written: publish both; every wave is
             // past its reads of step c-1 (W slot and exchange slot of c+1)
-            // (vmcnt retires in order and the DMAs are the youngest operations of the previous step: 0.  It also
-            // orders the in-place G stores behind every earlier logits load of the same bytes.)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (vmcnt retires in order: all but the raw-ring loads issued behind the previous k-step's DMAs.  It also
+            // orders the in-place G stores behind every earlier logits load of the same bytes: the youngest loads
+            // still flying are those of k-step c+4, the stores below overwrite bytes of k-steps <= c+2.)
+            if (X3_OFF(4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (FIRST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             x3_lds_barrier();
             const int ws = wb + (j & 1) * XG_WSLOT, xs = xa + (j & 1) * XG_XSLOT;
             u32x4 af[2][3], bf[8], bn[8];
@@ -670,43 +998,46 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 3072 + p * 1024));
-            if (!RNNT_XP(a.flags, 4096)) {
+            if (!X3_OFF(64)) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
             }
-            // while they land: G of k-step c+1 into the other exchange slot, and its logits ring refill
-            if (c + 1 < VC) produce(xr[(j + 1) & 3], c + 1);  // workgroup-uniform
-            xload(xr[(j + 1) & 3], c + 5);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(3)"  // the three exchange writes of produce() may still fly
+            asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
                            "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
                          :: "memory");
             // one product block: 16 MFMAs = (2 M tiles) x (8 column tiles) for A plane PA against the B plane held
-            // in `bcur`; optionally the next B plane's 8 fragment reads (NB: plane index, -1 none) and W DMA pieces
-            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c) {
-                constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value;
+            // in `bcur`; optionally the next B plane's 8 fragment reads (NB: plane index, -1 none), W DMA pieces of
+            // k-step c+1 (D0: first piece, -1 none) and production slices of G's k-step c+1 (S0: first slice, -1 none)
+            Prod P;
+            const bool prod_on = c + 1 < VC;  // workgroup-uniform
+            const Raw &rawn = xr[(j + 1) & 3];
+            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto s0_c) {
+                constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value, S0 = decltype(s0_c)::value;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if (!RNNT_XP(a.flags, 1024)) {
+                    if (!X3_OFF(1)) {
                         acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
                         acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
                     }
-                    if (NB >= 0 && !RNNT_XP(a.flags, 4096))
+                    if (NB >= 0 && !X3_OFF(64))
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
                     if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
+                    if (S0 >= 0 && S0 + q < 10 && prod_on && !(X3_OFF(32) && S0 + q < 8)) produce_slice(P, rawn, c + 1, (S0 < 0 ? 0 : S0) + q);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-#define XG_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
-            block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{});   // ah.bh   + DMA pieces 0-3
-            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<4>{});    // am.bh   + reads of W mid, DMA pieces 4-7
+            block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{}, X3Int<0>{});    // ah.bh + DMA 0-3, G slices 0-7 (exp2, corrections, split)
+            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<4>{}, X3Int<8>{});     // am.bh + reads of W mid, DMA 4-7, G slices 8-9 (exchange, stores)
             XG_WAIT8(bn);
-            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{});   // al.bh   + DMA pieces 8-11
-            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{});   // ah.bm   + reads of W lo (into the hi registers)
+            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // al.bh + DMA 8-11
+            // the raw ring refill comes AFTER the k-step's DMAs: vmcnt retires in order, and next k-step's wait for the
+            // DMAs must not also wait out these loads (HBM latency; they are needed 4 k-steps from now)
+            if (!X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5);
+            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
             XG_WAIT8(bf);
-            block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{});  // am.bm
-            block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+            block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // am.bm
+            block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued ring loads / DMAs
@@ -715,7 +1046,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     // ---- epilogue.  Accumulator register rr = 8rh + r7 of M tile (2wm + mt), column tile q: row (rr&3) + 8(rr>>2) +
     // 4half of its 32 = t row 2(2wm+mt) + rh, u slot 8(r7>>2) + (r7&3) + 4half; column 512hp + 256wn + 128(q>>2) +
     // 4i + (q&3).  hidden = hi + mid + lo of the planes (exact), through a raw buffer over the tile's rows.
-    if (RNNT_XP(a.flags, 16384)) return;
+    if (X3_OFF(16)) return;
     float (*s_red)[64][65] = (float (*)[64][65])s_dh;  // [wn][lane][8 u slots x 8 columns]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
     const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
@@ -818,6 +1149,8 @@ void launch_x3_pack_w(const X3Args &a, hipStream_t st)
 {
     const long nd = (long)((a.H + 511) / 512) * (a.V / 16) * 16 * 64;
     hipLaunchKernelGGL(k_x3_pack_w_dh, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a.W, (u32x4 *)a.wpack_dh, a.H, a.V, nd);
+    const long nf = (long)((a.V + 511) / 512) * (a.H / 16) * 16 * 64;
+    hipLaunchKernelGGL(k_x3_pack_w_fwd, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W, (u32x4 *)a.wpack_fwd, a.H, a.V, nf);
 }
 
 void launch_dhidden_x3(const X3Args &a, hipStream_t st)

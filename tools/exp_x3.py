@@ -22,8 +22,11 @@ def timeit(stage, n=5):
     return sorted(ts)[n // 2]
 names = {1: "fwd", 4: "dhidden", 6: "dw"}
 for stage in stages:
-    for flags, label in ((0, "shipped"), (1024, "no MFMA"), (8192, "no DMA"), (4096, "no fragment reads"), (1024 + 4096, "DMA only"),
+    extra = ((256, "no G stores"), (16384, "no epilogue"), (256 + 16384, "no G stores, no epilogue"), (256 + 8192, "no G stores, no DMA"),
+             (1024 + 256 + 4096 + 8192 + 16384, "production + barriers only")) if stage == 4 else ()
+    for flags, label in ((0, "shipped"),) + extra + ( (1024, "no MFMA"), (8192, "no DMA"), (4096, "no fragment reads"), (1024 + 4096, "DMA only"),
                          (8192 + 4096, "MFMA only"), (1024 + 8192, "reads only"), (1024 + 4096 + 8192, "skeleton (barriers)")):
+        if flags == 0 and label != "shipped": continue
         engine.lib().rnnt_engine_set_flags(flags)
         print(f"{names[stage]:8s} {label:24s} {timeit(stage):7.3f} ms", flush=True)
     engine.lib().rnnt_engine_set_flags(0)
