@@ -300,7 +300,9 @@ typedef struct rnnt_engine_ws_layout {
     size_t logits, hidden, denom_s, lpb_s, lpe_s, alpha_s, beta_s, coef, wpack, enc_copy;
     size_t slab_enc, slab_pred, slab_w, slab_b, counters, total, rows_pad;
     int n_ublk, n_ttile, n_split, D;
-    size_t g_lo, aux; /* RNNT_DTYPE_F32_BF16X3: lo plane of G; fp32 hidden + W pack of the _X3_FP32_ variants */
+    size_t g_lo;          /* RNNT_DTYPE_F32_BF16X3: lo plane of G */
+    size_t aux, aux_bytes; /* RNNT_DTYPE_F32_BF16X3: fp32 hidden + W pack of the RNNT_VARIANT_X3_FP32_* stages, placed BEHIND
+                            * `total` (aux == total): only a call with such a variant needs total + aux_bytes */
 } rnnt_engine_ws_layout;
 
 int rnnt_engine_workspace_layout(int B, int T, int U1, int H, int V, int dtype,

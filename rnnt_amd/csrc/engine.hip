@@ -92,7 +92,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->n_ublk = bf ? (U1 + 15) / 16 : x3 ? (U1 + 7) / 8 : (U1 + dhidden_gen_bu(T, U1) - 1) / dhidden_gen_bu(T, U1);
     L->n_ttile = (T + 3) / 4;  // dPred slabs: at most one per 4 t rows (the persistent kernel's 16-wide items)
     L->n_split = dw_splits(B, T, H, V, dtype);
-    L->g_lo = 0; L->aux = 0;
+    L->g_lo = 0; L->aux = 0; L->aux_bytes = 0;
     size_t o = 0;
     if (bf) {
         const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
@@ -126,10 +126,11 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
         const size_t tab = (2 * (size_t)B + 2) * 8, lst = (bf || x3) ? 0 : dw_list_bytes(B, T, U1, 16);
         L->counters = o; o += 1024 + align_up(tab > lst ? tab : lst);
     }
-    if (x3) {  // fp32 hidden + fp32 W pack of the stages that can run on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*)
-        L->aux = o; o += align_up((rows_pad + 16) * H * 4) + align_up(wpack_floats(H, V) * 4);
-    }
     L->total = o;
+    if (x3) {  // fp32 hidden + fp32 W pack of the stages that can run on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*):
+        // BEHIND `total` — only a call that asks for such a variant needs a workspace of total + aux_bytes
+        L->aux = o; L->aux_bytes = align_up((rows_pad + 16) * H * 4) + align_up(wpack_floats(H, V) * 4);
+    }
 }
 
 }  // namespace
@@ -288,6 +289,10 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.counter = (unsigned *)(ws + L.counters + 512); h.n_cu = device_cus();
         const bool f32_dh = (xflags & RNNT_VARIANT_X3_FP32_DH) != 0 || !x3_dhidden_ok(U1, H, V);
         const bool f32_fwd = (xflags & RNNT_VARIANT_X3_FP32_FWD) != 0 || !x3_fwd_ok(U1, H, V) || f32_dh;  // fp32 dHidden reads fp32 hidden
+        if ((f32_fwd || f32_dh) && ws_bytes < L.total + L.aux_bytes)
+            return fail(RNNT_ERR_WORKSPACE, "workspace %zu < %zu bytes: a stage on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*, or a "
+                        "shape k_joint_fwd_x3 / k_dhidden_x3 do not cover) needs total + aux_bytes of rnnt_engine_workspace_layout",
+                        ws_bytes, L.total + L.aux_bytes);
         float *hid32 = (float *)(ws + L.aux);
         float *wpack32 = (float *)(ws + L.aux + align_up((L.rows_pad + 16) * (size_t)H * 4));
         g.hidden = hid32;

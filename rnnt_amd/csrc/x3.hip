@@ -868,6 +868,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
         return;
     }
 
+    const bool wave_stores = __any(pexists) && !X3_OFF(2);  // wave-uniform: the G stores below are issued at all
     CellCoef cf = a.coef[pexists ? pcell : 0];
     const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
     if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
@@ -983,11 +984,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             const int c = c0 + j;
             // W k-step c landed (this wave's share), G fragments of step c written: publish both; every wave is
             // past its reads of step c-1 (W slot and exchange slot of c+1)
-            // (vmcnt retires in order: all but the raw-ring loads issued behind the previous k-step's DMAs.  It also
-            // orders the in-place G stores behind every earlier logits load of the same bytes: the youngest loads
-            // still flying are those of k-step c+4, the stores below overwrite bytes of k-steps <= c+2.)
-            if (X3_OFF(4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (FIRST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // (vmcnt retires in order: all but the G stores and raw-ring loads issued behind the previous k-step's
+            // DMAs.  In-place safety: a store of k-step s's G overwrites logits bytes of k-steps <= s+1, every one of
+            // them loaded — and waited for by this counter — at least two k-steps before the store is issued.)
+            if (X3_OFF(4) || X3_OFF(2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (FIRST && wave_stores) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // 3 G stores + 2 raw loads behind the DMAs
+            else if (FIRST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // a wave without an existing cell issues no store
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             x3_lds_barrier();
             const int ws = wb + (j & 1) * XG_WSLOT, xs = xa + (j & 1) * XG_XSLOT;
@@ -1023,16 +1025,18 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                     if (NB >= 0 && !X3_OFF(64))
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
                     if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
-                    if (S0 >= 0 && S0 + q < 10 && prod_on && !(X3_OFF(32) && S0 + q < 8)) produce_slice(P, rawn, c + 1, (S0 < 0 ? 0 : S0) + q);
+                    if (S0 >= 0 && S0 + q < 9 && prod_on && !(X3_OFF(32) && S0 + q < 8)) produce_slice(P, rawn, c + 1, (S0 < 0 ? 0 : S0) + q);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{}, X3Int<0>{});    // ah.bh + DMA 0-3, G slices 0-7 (exp2, corrections, split)
-            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<4>{}, X3Int<8>{});     // am.bh + reads of W mid, DMA 4-7, G slices 8-9 (exchange, stores)
+            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<4>{}, X3Int<8>{});     // am.bh + reads of W mid, DMA 4-7, G slice 8 (exchange)
             XG_WAIT8(bn);
             block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // al.bh + DMA 8-11
-            // the raw ring refill comes AFTER the k-step's DMAs: vmcnt retires in order, and next k-step's wait for the
-            // DMAs must not also wait out these loads (HBM latency; they are needed 4 k-steps from now)
+            // G's stores and the raw ring refill come AFTER the k-step's DMAs: vmcnt retires in order, and the next
+            // k-step's wait for the DMAs must not also wait out a store acknowledgement or an HBM load (needed 4
+            // k-steps from now); they get one more k-step
+            if (prod_on) produce_slice(P, rawn, c + 1, 9);
             if (!X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5);
             block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
             XG_WAIT8(bf);
@@ -1051,50 +1055,41 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
     const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
     const bool colok[2] = {colg[0] < H, colg[1] < H};
-    const long cell0 = ((long)b * T + t0) * U1 + u0;
-    const long rows_left = a.rows_alloc - cell0;
-    const long span0 = (long)(XG_BT - 1) * U1 + XG_BU < rows_left ? (long)(XG_BT - 1) * U1 + XG_BU : rows_left;
-    const long rows_utt = (long)(T - t0) * U1 - u0;  // never into the next utterance's rows
-    const long span = span0 < rows_utt ? span0 : rows_utt;
-    __amdgpu_buffer_rsrc_t hrs[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-        hrs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hidden + p * a.plane_stride + cell0 * H), 0, (int)(span * H * 2), 0x00020000);
-    const unsigned hvoff[2] = {colok[0] ? (unsigned)(((4 * half) * H + colg[0]) * 2) : 0xfffffff0u,
-                               colok[1] ? (unsigned)(((4 * half) * H + colg[1]) * 2) : 0xfffffff0u};
+    // hidden is RECOMPUTED from enc and pred (two small, cache-resident operands; the same fast_tanh_sum4 as the
+    // forward's prologue, so bit for bit the value whose planes the GEMMs multiplied) instead of re-reading its
+    // three planes: 6 bytes per element of HBM traffic in a kernel that already moves 68 GB in ~25 ms.
+    // Rows outside the lattice have G = 0 and therefore an exactly zero accumulator: any finite value will do.
     float psum[8][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
         for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
+    f32x4 pr[8][2];  // pred rows of this lane's 8 u slots, its 2 x 4 columns (zero where u >= U1 or the column >= H)
+#pragma unroll
+    for (int r7 = 0; r7 < 8; ++r7) {
+        const int u = u0 + 8 * (r7 >> 2) + (r7 & 3) + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            pr[r7][g] = (u < U1 && colok[g]) ? *(const f32x4 *)(a.pred + ((long)b * U1 + u) * H + colg[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
             const int tl = 2 * (2 * wm + mt) + rh;  // t row inside the tile
+            const int t = t0 + tl;
             float esum[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) esum[q] = 0.f;
-            u32x2 hq[8][2][3];
+            f32x4 er[2];
 #pragma unroll
-            for (int r7 = 0; r7 < 8; ++r7) {
-                const unsigned soff = (unsigned)((tl * U1 + 8 * (r7 >> 2) + (r7 & 3)) * H) * 2u;
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        hq[r7][g][p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(hrs[p], hvoff[g], soff, 0));
-            }
+            for (int g = 0; g < 2; ++g)
+                er[g] = (t < T && colok[g]) ? *(const f32x4 *)(a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + colg[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    float hv[4];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        hv[2 * e] = (x3_lo(hq[r7][g][0][e]) + x3_lo(hq[r7][g][1][e])) + x3_lo(hq[r7][g][2][e]);
-                        hv[2 * e + 1] = (x3_hi(hq[r7][g][0][e]) + x3_hi(hq[r7][g][1][e])) + x3_hi(hq[r7][g][2][e]);
-                    }
+                    const f32x4 hv = fast_tanh_sum4(er[g], pr[r7][g]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float d = acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - hv[q] * hv[q]);
@@ -1104,7 +1099,6 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                 }
 #pragma unroll
             for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
-            const int t = t0 + tl;
             if (half == 0 && t < Tb) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)

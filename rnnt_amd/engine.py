@@ -122,7 +122,7 @@ class WsLayout(ctypes.Structure):
         "logits", "hidden", "denom_s", "lpb_s", "lpe_s", "alpha_s", "beta_s", "coef", "wpack",
         "enc_copy", "slab_enc", "slab_pred", "slab_w", "slab_b", "counters", "total", "rows_pad")] + [
         (n, ctypes.c_int) for n in ("n_ublk", "n_ttile", "n_split", "D")] + [
-        (n, ctypes.c_size_t) for n in ("g_lo", "aux")]
+        (n, ctypes.c_size_t) for n in ("g_lo", "aux", "aux_bytes")]
 
 
 def build(force: bool = False) -> str:
@@ -387,7 +387,10 @@ def joint_loss_fwd_bwd(enc, pred, W, bias, targets, logit_lens, target_lens, bla
             _require_dtype(torch.float32, **{f"outs[{i}]": o for i, o in enumerate(outs)})
             _require_contiguous(**{f"outs[{i}]": o for i, o in enumerate(outs)})
         code = dtype_code(dtype)
-        ws = workspace(dev, workspace_bytes(B, T, U1, H, V, code))
+        need = workspace_bytes(B, T, U1, H, V, code)
+        if variant & (VARIANT_X3_FP32_FWD | VARIANT_X3_FP32_DH):
+            need += layout(B, T, U1, H, V, code).aux_bytes  # fp32 hidden + W pack of the substituted stages
+        ws = workspace(dev, need)
         args = _fused_args(enc, pred, W, bias, targets, logit_lens, target_lens, blank, grad_scale,
                            outs, ws, code)
         if stage_mask is not None or variant:
