@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
         const int H8 = H / 8;
         const int rstep = 256 / H8 > 0 ? 256 / H8 : 1;
         const int r0 = tid / H8, h = (tid - r0 * H8) * 8;
-        if (r0 < rstep) {
+        if (r0 < rstep && !X3_OFF(128)) {
             long c = row0 + r0;
             int u = (int)(c % U1);
             long bt = c / U1;
@@ -570,24 +570,31 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
     const int xa = lds0 + 2 * XF_WSLOT + (2 * wm) * 3072 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                 // W read: tiles 8wn .. 8wn+7 of each plane
     const u32x4 *wsrc = (const u32x4 *)a.wpack_fwd + (wave * 12) * 64 + lane;
-    // A DMA: wave w fetches M tile w (3 pieces: one per plane); lane (r, h): 16 bytes of row 32w + r at k = 8h
+    // Operand staging, per k-step and wave: 12 pieces of W (pieces 12w .. 12w+11 of the k-step's 48; a piece = one
+    // (plane, tile) = 1 KiB) and 3 of A (M tile w, one per plane; lane (r, h): 16 bytes of row 32w + r at k = 8h).
+    // Global -> VGPR -> LDS, not LDS-DMA: a DMA piece costs the issuing wave 60-180 cycles of issue (guide, LDS-DMA
+    // piece issue cost) — 15 of them per 96 MFMAs were a third of a k-step — a register load ~nothing and a
+    // ds_write_b128 13.  The registers carry k-step c+1 while k-step c computes: written to the ring slot of c+1 in
+    // the first MFMA blocks of k-step c (every wave is past its reads of that slot: barrier), reloaded with k-step
+    // c+2 in the later blocks.
     __amdgpu_buffer_rsrc_t ars[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
         ars[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hidden + p * a.plane_stride + row0 * H), 0, 128 * H * 2, 0x00020000);
     const int avoff = ((32 * wave + i) * H + 8 * half) * 2;
     const int NS = npass * KC;  // k-steps of the tile
-    // piece n (0..14) of this wave's share of k-step `cs` (its k index inside the pass: `kcs`) -> ring slots cs & 1
-    auto dma = [&](int cs, int kcs, int n) {
+    u32x4 stg[15];
+    auto stage_load = [&](int cs, int kcs, int n) {  // piece n (0..14) of k-step cs (k index inside its pass: kcs)
         if (X3_OFF(8)) return;
-        if (n < 12) {
-            __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cs * 3072 + n * 64),
-                                             (lds_vptr)(s_fw + (cs & 1) * XF_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
-        } else {
-            const int p = n - 12;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars[p], (lds_vptr)(s_fw + 2 * XF_WSLOT + (cs & 1) * XF_ASLOT + wave * 3072 + p * 1024),
-                                                     16, avoff, 32 * kcs, 0, 0);
-        }
+        if (n < 12) stg[n] = wsrc[(long)cs * 3072 + n * 64];
+        else stg[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars[n - 12], avoff, 32 * kcs, 0));
+    };
+    const int wst = lds0 + wave * 12288 + 16 * lane;                      // W ring write base (slot 0)
+    const int ast = lds0 + 2 * XF_WSLOT + wave * 3072 + 16 * lane;        // A ring write base (slot 0)
+    auto stage_write = [&](int slot, int n) {  // piece n of the staged k-step -> ring slot
+        if (X3_OFF(8)) return;
+        if (n < 12) asm volatile("ds_write_b128 %0, %1" :: "v"(wst + slot * XF_WSLOT + n * 1024), "v"(stg[n]) : "memory");
+        else asm volatile("ds_write_b128 %0, %1" :: "v"(ast + slot * XF_ASLOT + (n - 12) * 1024), "v"(stg[n]) : "memory");
     };
 
     // running (max, sum exp) of every row over the columns seen so far, per column half (wn): s_part[wn][row], kept
@@ -607,7 +614,11 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
                 for (int r = 0; r < 16; ++r) acc[mt][q][r] = q < 4 ? b0[q] : b1[q - 4];
     };
 #pragma unroll
-    for (int n = 0; n < 15; ++n) dma(0, 0, n);
+    for (int n = 0; n < 15; ++n) stage_load(0, 0, n);
+#pragma unroll
+    for (int n = 0; n < 15; ++n) stage_write(0, n);
+#pragma unroll
+    for (int n = 0; n < 15; ++n) stage_load(NS > 1 ? 1 : 0, KC > 1 ? 1 : 0, n);
 
     int cs = 0;
     for (int pass = 0; pass < npass; ++pass) {
@@ -615,11 +626,11 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
       // the k loop makes hipcc carry the 256 accumulator registers through VGPR phis and spill hundreds)
       acc_init(pass);
       for (int kc = 0; kc < KC; ++kc, ++cs) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // k-step cs landed (this wave's share); pass-end stores done
-        x3_lds_barrier();
+        x3_lds_barrier();  // ring slot cs & 1 written by every wave (ds_write + lgkmcnt(0)); slot of cs+1 read by all
         const int ws = wb + (cs & 1) * XF_WSLOT, xs = xa + (cs & 1) * XF_ASLOT;
-        // the next k-step (the last one re-fetches itself: never read)
-        const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = cs + 1 < NS ? (kc + 1 < KC ? kc + 1 : 0) : kc;
+        // the k-step after next (past the end: re-fetches the last one, never read)
+        const int csn = cs + 2 < NS ? cs + 2 : NS - 1;
+        const int kcn = cs + 2 < NS ? (kc + 2 < KC ? kc + 2 : kc + 2 - KC) : KC - 1;
         u32x4 af[2][3], bf[8], bn[8];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -641,15 +652,17 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
                     acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
                 }
                 if (NB >= 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
-                if (D0 >= 0 && D0 + q < 15) dma(csn, kcn, (D0 < 0 ? 0 : D0) + q);
+                // D0 in 0..14: ring writes of the staged pieces D0+q (k-step cs+1); D0 in 16..30: loads of k-step cs+2
+                if (D0 >= 0 && D0 < 16 && D0 + q < 15) stage_write((cs + 1) & 1, (D0 < 0 ? 0 : D0) + q);
+                if (D0 >= 16 && D0 - 16 + q < 15) stage_load(csn, kcn, (D0 < 16 ? 0 : D0 - 16) + q);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{});   // ah.bh + DMA 0-7
-        block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<8>{});    // am.bh + reads of W mid, DMA 8-14
+        block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{});   // ah.bh + ring writes 0-7
+        block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<8>{});    // am.bh + reads of W mid, ring writes 8-14
         XG_WAIT8(bn);
-        block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // al.bh
-        block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
+        block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<16>{});  // al.bh + loads 0-7 of k-step cs+2
+        block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<24>{});   // ah.bm + reads of W lo (into the hi registers), loads 8-14
         XG_WAIT8(bf);
         block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{});  // am.bm
         block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // ah.bl

@@ -556,7 +556,7 @@ def test_inputs_ending_at_unmapped_pages():
     """Input OVER-READS (the class of the round-2 bf16 fault: a bias read 512 B past the vector at V = 128,
     commit 1f6212f — invisible to every parity test because the neighbouring allocation was mapped): every
     input of the fused call placed so that it ends at an unmapped page (HIP virtual-memory API,
-    tools/guard_alloc.hip) for 9 fused shapes on both routes — V = 128 bf16 and H = 1024 among them — plus one
+    tools/guard_alloc.hip) for 12 fused shapes on the three routes — V = 128 bf16 and H = 1024 among them — plus one
     call of every other entry point.  Runs tools/guard_sweep.py --slice in a CHILD process: a memory fault
     kills the child and fails this test, the rest of the run goes on.  Run once; never looped."""
     import subprocess
@@ -570,7 +570,7 @@ def test_inputs_ending_at_unmapped_pages():
                          capture_output=True, text=True, timeout=600, cwd=root)
     tail = (out.stdout[-1500:] + "\n" + out.stderr[-1500:])
     assert out.returncode == 0, "guard sweep died (memory fault = an input over-read):\n" + tail
-    assert "guard sweep clean: 9 cases" in out.stdout and "guard sweep of the other entry points clean" in out.stdout, tail
+    assert "guard sweep clean: 12 cases" in out.stdout and "guard sweep of the other entry points clean" in out.stdout, tail
 
 
 # ---------------------------------------------------------------- full-size properties
