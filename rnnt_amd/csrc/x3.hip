@@ -513,165 +513,221 @@ size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
 // ---------------------------------------------------------------------------------------
 #define XF_WSLOT 49152
 #define XF_ASLOT 12288
-__global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
+__global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int ntiles)
 {
-    // [0, 96 KiB): W ring;  [96, 120 KiB): A ring;  then: s_den[128], s_part[2][128][2]
+    // [0, 96 KiB): W ring;  [96, 120 KiB): A ring;  then: s_den[128], s_part[2][128][2], s_next[2]
     extern __shared__ __attribute__((aligned(1024))) char s_fw[];
     float *s_den = (float *)(s_fw + 2 * XF_WSLOT + 2 * XF_ASLOT);
     float *s_part = s_den + 128;  // [wn][row][max, sum]
+    int *s_next = (int *)(s_part + 512);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, half = lane >> 5;
     const int H = a.H, V = a.V, KC = H / 16, U1 = a.U1, T = a.T;
     const int npass = (V + 511) / 512;
+    const int NS = npass * KC;  // k-steps of a tile
     const long cells = (long)a.B * T * U1;
-    const long row0 = (long)blockIdx.x * 128;
-    {   // tiles with no live cell: the row padding past the last cell, and tiles that lie entirely in the dead
-        // time steps (t >= T_b) of one utterance — their logits are never read (k_dhidden_x3 zero-fills the G
-        // rows of dead tiles itself); hidden must still be finite everywhere (k_dw_x3 multiplies it by zeros)
-        if (row0 >= cells) return;
-    }
-    // ---- prologue: hidden planes of the tile's 128 cells.  A thread owns 8 columns of every (256/(H/8))-th row.
-    {
-        const int H8 = H / 8;
-        const int rstep = 256 / H8 > 0 ? 256 / H8 : 1;
-        const int r0 = tid / H8, h = (tid - r0 * H8) * 8;
-        if (r0 < rstep && !X3_OFF(128)) {
-            long c = row0 + r0;
-            int u = (int)(c % U1);
-            long bt = c / U1;
-            int t = (int)(bt % T), b = (int)(bt / T);
-            const long ps = a.plane_stride / 8;
-            u32x4 *hid = (u32x4 *)a.hidden;
-            for (int r = r0; r < 128 && c < cells; r += rstep, c += rstep) {
-                const float *ep = a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + h;
-                const float *pp = a.pred + ((long)b * U1 + u) * H + h;
-                const f32x4 t0 = fast_tanh_sum4(*(const f32x4 *)ep, *(const f32x4 *)pp);
-                const f32x4 t1 = fast_tanh_sum4(*(const f32x4 *)(ep + 4), *(const f32x4 *)(pp + 4));
-                u32x4 ph, pm, pl;
-                X3_SPLIT4(t0, ph, pm, pl, 0);
-                X3_SPLIT4(t1, ph, pm, pl, 2);
-                u32x4 *o = hid + c * H8 + h / 8;
-                o[0] = ph; o[ps] = pm; o[2 * ps] = pl;
-                u += rstep;
-                while (u >= U1) { u -= U1; if (++t == T) { t = 0; ++b; } }
-            }
-        }
-    }
-    {   // dead tile (entirely in the time steps past one utterance's length): hidden written, nothing else to do
-        const long per = (long)T * U1, c_last = row0 + 127;
-        const long b_first = row0 / per;
-        if (c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T)) return;
-    }
-    __syncthreads();  // the tile's hidden rows are stored (vmcnt(0)) and every wave is past them
+    typedef float f2 __attribute__((ext_vector_type(2)));
 
     const int lds0 = (int)(size_t)(lds_vptr)s_fw;
     const int xa = lds0 + 2 * XF_WSLOT + (2 * wm) * 3072 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
+    const int xw = lds0 + 2 * XF_WSLOT + wave * 3072 + 16 * lane;       // A write: M tile `wave` (this lane's own fragment slot)
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                 // W read: tiles 8wn .. 8wn+7 of each plane
     const u32x4 *wsrc = (const u32x4 *)a.wpack_fwd + (wave * 12) * 64 + lane;
-    // Operand staging, per k-step and wave: 12 pieces of W (pieces 12w .. 12w+11 of the k-step's 48; a piece = one
-    // (plane, tile) = 1 KiB) and 3 of A (M tile w, one per plane; lane (r, h): 16 bytes of row 32w + r at k = 8h).
-    // Global -> VGPR -> LDS, not LDS-DMA: a DMA piece costs the issuing wave 60-180 cycles of issue (guide, LDS-DMA
-    // piece issue cost) — 15 of them per 96 MFMAs were a third of a k-step — a register load ~nothing and a
-    // ds_write_b128 13.  The registers carry k-step c+1 while k-step c computes: written to the ring slot of c+1 in
-    // the first MFMA blocks of k-step c (every wave is past its reads of that slot: barrier), reloaded with k-step
-    // c+2 in the later blocks.
-    __amdgpu_buffer_rsrc_t ars[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-        ars[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.hidden + p * a.plane_stride + row0 * H), 0, 128 * H * 2, 0x00020000);
-    const int avoff = ((32 * wave + i) * H + 8 * half) * 2;
-    const int NS = npass * KC;  // k-steps of the tile
-    u32x4 stg[15];
-    auto stage_load = [&](int cs, int kcs, int n) {  // piece n (0..14) of k-step cs (k index inside its pass: kcs)
-        if (X3_OFF(8)) return;
-        if (n < 12) stg[n] = wsrc[(long)cs * 3072 + n * 64];
-        else stg[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars[n - 12], avoff, 32 * kcs, 0));
-    };
-    const int wst = lds0 + wave * 12288 + 16 * lane;                      // W ring write base (slot 0)
-    const int ast = lds0 + 2 * XF_WSLOT + wave * 3072 + 16 * lane;        // A ring write base (slot 0)
-    auto stage_write = [&](int slot, int n) {  // piece n of the staged k-step -> ring slot
-        if (X3_OFF(8)) return;
-        if (n < 12) asm volatile("ds_write_b128 %0, %1" :: "v"(wst + slot * XF_WSLOT + n * 1024), "v"(stg[n]) : "memory");
-        else asm volatile("ds_write_b128 %0, %1" :: "v"(ast + slot * XF_ASLOT + (n - 12) * 1024), "v"(stg[n]) : "memory");
-    };
 
-    // running (max, sum exp) of every row over the columns seen so far, per column half (wn): s_part[wn][row], kept
-    // by the lanes 31 / 63 that end up with a row slot's wave-level statistics (64 per-lane register pairs instead
-    // made hipcc spill 300 registers around the main loop)
-    for (int k = tid; k < 256; k += 256) { s_part[2 * k] = RNNT_NEG_INF; s_part[2 * k + 1] = 0.f; }
-    f32x16 acc[2][8];
-    auto acc_init = [&](int pass) {  // the bias of this lane's 2 x 4 adjacent columns of the pass
-        const int c0 = 512 * pass + 256 * wn + 4 * i;
-        const f32x4 b0 = c0 < V ? *(const f32x4 *)(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 b1 = c0 + 128 < V ? *(const f32x4 *)(a.bias + c0 + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][q][r] = q < 4 ? b0[q] : b1[q - 4];
-    };
-#pragma unroll
-    for (int n = 0; n < 15; ++n) stage_load(0, 0, n);
-#pragma unroll
-    for (int n = 0; n < 15; ++n) stage_write(0, n);
-#pragma unroll
-    for (int n = 0; n < 15; ++n) stage_load(NS > 1 ? 1 : 0, KC > 1 ? 1 : 0, n);
+    // Persistent workgroups (one per CU: 120 KiB of LDS), tiles from one atomic counter, the next tile requested a
+    // tile ahead.
+    if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    int tile = s_next[0];
+    for (int it = 1; tile < ntiles; ++it) {
+        if (tid == 0) s_next[it & 1] = (int)atomicAdd(a.counter, 1u);
+        const long row0 = (long)tile * 128;
+        // running (max, sum exp) of every row over the columns seen so far, per column half (wn): s_part[wn][row],
+        // kept by the lanes 31 / 63 that end up with a row slot's wave-level statistics
+        for (int k = tid; k < 256; k += 256) { s_part[2 * k] = RNNT_NEG_INF; s_part[2 * k + 1] = 0.f; }
+        __syncthreads();  // s_next, s_part visible; every wave is past the previous tile's LDS reads
+        const int next = s_next[it & 1];
+        // A tile entirely in the time steps past one utterance's length: its logits are never read (k_dhidden_x3
+        // zero-fills the G rows of dead tiles itself), but its hidden rows must be finite (k_dw_x3 multiplies them by
+        // zeros): such a tile runs the production of its first pass WITHOUT the MFMAs (DEAD below).
+        bool dead;
+        {
+            const long per = (long)T * U1, c_last = row0 + 127;
+            const long b_first = row0 / per;
+            dead = c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T);
+        }
 
-    int cs = 0;
-    for (int pass = 0; pass < npass; ++pass) {
-      // (accumulators initialised by plain assignment at the top of a loop: a conditional re-initialisation inside
-      // the k loop makes hipcc carry the 256 accumulator registers through VGPR phis and spill hundreds)
-      acc_init(pass);
-      for (int kc = 0; kc < KC; ++kc, ++cs) {
-        x3_lds_barrier();  // ring slot cs & 1 written by every wave (ds_write + lgkmcnt(0)); slot of cs+1 read by all
-        const int ws = wb + (cs & 1) * XF_WSLOT, xs = xa + (cs & 1) * XF_ASLOT;
-        // the k-step after next (past the end: re-fetches the last one, never read)
-        const int csn = cs + 2 < NS ? cs + 2 : NS - 1;
-        const int kcn = cs + 2 < NS ? (kc + 2 < KC ? kc + 2 : kc + 2 - KC) : KC - 1;
-        u32x4 af[2][3], bf[8], bn[8];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 3072 + p * 1024));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
-                       "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
-                     :: "memory");
-        auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c) {
-            constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (!X3_OFF(1)) {
-                    acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
-                    acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
+        // ---- hidden = tanh(enc + pred), produced per k-step IN FRAGMENT ORDER by the lane that owns the slot: lane
+        // (i, half) of wave w holds row 32w + i, k = 16c + 8*half .. +7 of the MFMA A operand — 8 values from 2 x 32
+        // bytes of enc and pred (small, cache-resident operands), split three ways, 16 bytes per plane into the LDS
+        // ring of k-step c+1 (every wave reads its two M tiles from there) and, in the first pass, to the hidden
+        // planes in memory for k_dw_x3.  The forward never re-reads hidden from memory: later passes produce it again
+        // (~130 instructions per lane and k-step, threaded through the gaps of 96 MFMAs).
+        const long prow = row0 + 32 * wave + i;
+        const long pc_ = prow < cells ? prow : cells - 1;  // rows past the lattice (last tile): any valid cell, never stored
+        const int pu = (int)(pc_ % U1);
+        const long pbt = pc_ / U1;
+        const int pt = (int)(pbt % T), pb = (int)(pbt / T);
+        const float *ep = a.enc + (long)pb * a.enc_sb + (long)pt * a.enc_st + 8 * half;
+        const float *pp = a.pred + ((long)pb * U1 + pu) * H + 8 * half;
+        const bool prow_ok = prow < cells;
+        u32x4 *hdst = (u32x4 *)a.hidden + prow * (H / 8) + half;  // + 2c: this lane's 16 bytes of k-step c; planes `ps` apart
+        const long ps = a.plane_stride / 8;
+        struct Opd { f32x4 e0, e1, p0, p1; };
+        struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm, pl; };
+        auto op_load = [&](Opd &o, int kcs) {  // operands of k index kcs (inside a pass)
+            o.e0 = *(const f32x4 *)(ep + 16 * kcs); o.e1 = *(const f32x4 *)(ep + 16 * kcs + 4);
+            o.p0 = *(const f32x4 *)(pp + 16 * kcs); o.p1 = *(const f32x4 *)(pp + 16 * kcs + 4);
+        };
+        // pieces 0-7: tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 3-way split
+        // of each pair (hi, then mid + lo); 16: the three ring writes
+        auto prod_piece = [&](Prod &P, const Opd &o, int slot, int k) {
+            if (k < 8) {
+                const int j = k >> 1;
+                if (!(k & 1)) {
+                    const f32x4 &e = j < 2 ? o.e0 : o.e1, &pv = j < 2 ? o.p0 : o.p1;
+                    const int q = 2 * (j & 1);
+                    const f2 x = {e[q] + pv[q], e[q + 1] + pv[q + 1]};
+                    const f2 av = x * (2.0f * RNNT_LOG2E);
+                    P.w[j] = f2{__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+                } else {
+                    const f2 ex = P.w[j] + 1.0f;
+                    const f2 rr = {__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+                    P.w[j] = 1.0f - 2.0f * rr;
                 }
-                if (NB >= 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
-                // D0 in 0..14: ring writes of the staged pieces D0+q (k-step cs+1); D0 in 16..30: loads of k-step cs+2
-                if (D0 >= 0 && D0 < 16 && D0 + q < 15) stage_write((cs + 1) & 1, (D0 < 0 ? 0 : D0) + q);
-                if (D0 >= 16 && D0 - 16 + q < 15) stage_load(csn, kcn, (D0 < 16 ? 0 : D0 - 16) + q);
-                __builtin_amdgcn_sched_barrier(0);
+            } else if (k < 16) {
+                const int j = (k - 8) >> 1;
+                if (!(k & 1)) {
+                    const unsigned hh = x3_pack(P.w[j][0], P.w[j][1]);
+                    P.ph[j] = hh;
+                    P.ra = P.w[j][0] - x3_lo(hh); P.rb = P.w[j][1] - x3_hi(hh);
+                } else {
+                    const unsigned mm = x3_pack(P.ra, P.rb);
+                    P.pm[j] = mm;
+                    P.pl[j] = x3_pack(P.ra - x3_lo(mm), P.rb - x3_hi(mm));
+                }
+            } else {
+                const int dst = xw + slot * XF_ASLOT;
+                asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(P.ph) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(P.pl) : "memory");
             }
         };
-        block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{});   // ah.bh + ring writes 0-7
-        block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<8>{});    // am.bh + reads of W mid, ring writes 8-14
-        XG_WAIT8(bn);
-        block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<16>{});  // al.bh + loads 0-7 of k-step cs+2
-        block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<24>{});   // ah.bm + reads of W lo (into the hi registers), loads 8-14
-        XG_WAIT8(bf);
-        block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{});  // am.bm
-        block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
-      }
-      // pass complete: store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column groups exist
-      // or not for the whole wave.  The row loop is ONE basic block per case (no branch inside: with branches hipcc
-      // hoists all 256 accumulator reads in front of the first store and spills); the store address is a scalar
-      // row pointer + one 32-bit per-lane offset.
-      if (!X3_OFF(16)) {
+        auto hid_store = [&](const Prod &P, int kcs) {
+            if (prow_ok && !X3_OFF(128)) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; hdst[2 * kcs + 2 * ps] = P.pl; }
+        };
+        // piece n (0..11) of this wave's share of W k-step cs -> ring slot cs & 1
+        auto wdma = [&](int cs, int n) {
+            if (X3_OFF(8)) return;
+            __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cs * 3072 + n * 64),
+                                             (lds_vptr)(s_fw + (cs & 1) * XF_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
+        };
+
+        if (dead) {  // hidden rows only (finite values for k_dw_x3), no products
+            for (int kc = 0; kc < KC; ++kc) {
+                Opd o; Prod P;
+                op_load(o, kc);
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, 0, pc);
+                hid_store(P, kc);
+            }
+            tile = next;
+            continue;
+        }
+
+        f32x16 acc[2][8];
+        auto acc_init = [&](int pass) {  // the bias of this lane's 2 x 4 adjacent columns of the pass
+            const int c0 = 512 * pass + 256 * wn + 4 * i;
+            const f32x4 b0 = c0 < V ? *(const f32x4 *)(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = c0 + 128 < V ? *(const f32x4 *)(a.bias + c0 + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][q][r] = q < 4 ? b0[q] : b1[q - 4];
+        };
+        // pipeline prologue: W of k-step 0 by DMA; A of k-step 0 produced, stored, written to ring slot 0; operands of
+        // k-step 1 requested
+        Opd onext;
+        {
+#pragma unroll
+            for (int n = 0; n < 12; ++n) wdma(0, n);
+            Opd o; Prod P;
+            op_load(o, 0);
+            op_load(onext, KC > 1 ? 1 : 0);
+#pragma unroll
+            for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, 0, pc);
+            hid_store(P, 0);
+        }
+
+        int cs = 0;
+        // one pass; STORE: the first — the produced planes also go to memory.  Two straight-line instantiations, the
+        // first pass outside the loop over the others (a branch between two k loops, like a conditional accumulator
+        // re-initialisation inside one, makes hipcc carry the 256 accumulator registers through VGPR phis and spill)
+        auto run_pass = [&](auto store_c, const int pass) {
+          acc_init(pass);
+          // one k-step; STORE: first pass — the produced planes also go to memory.  Two straight-line instantiations
+          // (hipcc counts vmcnt exactly only through straight-line code).
+          constexpr bool STORE = decltype(store_c)::value != 0;
+          for (int kc = 0; kc < KC; ++kc, ++cs) {
+            // W of k-step cs landed (this wave's share).  vmcnt retires in order: behind a k-step's DMAs come only its
+            // 4 operand loads and (first pass) 3 hidden stores, which stay in flight; the first k-step of a pass also
+            // follows the previous pass's logits stores
+            if (kc == 0 || X3_OFF(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STORE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            x3_lds_barrier();  // publishes W slot and A slot of k-step cs; every wave is past its reads of cs-1
+            const int ws = wb + (cs & 1) * XF_WSLOT, xs = xa + (cs & 1) * XF_ASLOT;
+            // the next k-step (past the end: its own, never read) and the one after (operand loads)
+            const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
+            Opd ocur = onext;  // operands of k-step cs+1 (requested during the previous k-step)
+            Prod P;
+            u32x4 af[2][3], bf[8], bn[8];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 3072 + p * 1024));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
+                           "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
+                         :: "memory");
+            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto pb_c) {
+                constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value, PB = decltype(pb_c)::value;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!X3_OFF(1)) {
+                        acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
+                        acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
+                    }
+                    if (NB >= 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
+                    // D0: W DMA pieces D0+q of k-step cs+1; PB: production pieces PB+q of A's k-step cs+1
+                    if (D0 >= 0 && D0 + q < 12) wdma(csn, (D0 < 0 ? 0 : D0) + q);
+                    if (PB >= 0 && PB + q < 17) prod_piece(P, ocur, (cs + 1) & 1, (PB < 0 ? 0 : PB) + q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{}, X3Int<-1>{});   // ah.bh + DMA 0-7
+            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<8>{}, X3Int<-1>{});    // am.bh + reads of W mid, DMA 8-11
+            XG_WAIT8(bn);
+            op_load(onext, kcnn);  // operands of k-step cs+2: behind the DMAs (they are needed a whole k-step from now)
+            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<0>{});   // al.bh + A(cs+1): tanh pieces
+            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<8>{});    // ah.bm + reads of W lo, A(cs+1): split pieces
+            XG_WAIT8(bf);
+            block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<16>{});  // am.bm + A(cs+1): ring writes
+            if (STORE && kc + 1 < KC) hid_store(P, kc + 1);                    // (the youngest memory operations of the k-step)
+            block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+            (void)kcn;
+          }
+          // pass complete: store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column groups exist
+          // or not for the whole wave.  The row loop is ONE basic block per case; the store address is a scalar row
+          // pointer + one 32-bit per-lane offset.
+          if (!X3_OFF(16)) {
             const int cw = 512 * pass + 256 * wn;
             const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
             char *tile_base = (char *)(a.logits + row0 * V + cw);
@@ -681,12 +737,6 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        // the accumulators are "redefined" in front of every row slot: hipcc cannot hoist their
-                        // 256 reads (v_accvgpr_read) in front of the first store and spill them
-#ifdef X3_PIN_ACC
-                        asm volatile("" : "+a"(acc[mt][0]), "+a"(acc[mt][1]), "+a"(acc[mt][2]), "+a"(acc[mt][3]),
-                                          "+a"(acc[mt][4]), "+a"(acc[mt][5]), "+a"(acc[mt][6]), "+a"(acc[mt][7]));
-#endif
                         // accumulator reads spelled as (volatile) asm: they stay here, one row slot at a time — left to
                         // hipcc, all 256 v_accvgpr_read are hoisted in front of the first store and spilled
                         f32x4 o0, o1;
@@ -714,13 +764,13 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
                             if (BOTH)
                                 e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
                                      (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
-                            const float S = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
+                            const float S_ = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
                             if (i == 31) {
                                 float *sp = s_part + (wn * 128 + 32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
                                 const float m_o = sp[0], s_o = sp[1];
                                 const float mn = fmaxf(m_o, M);
                                 sp[0] = mn;
-                                sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                                sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
@@ -728,48 +778,52 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a)
             };
             if (cw + 128 < V) epilogue(X3Int<1>{});
             else if (cw < V) epilogue(X3Int<0>{});
-      }
-    }
+          }
+        };
+        run_pass(X3Int<1>{}, 0);
+        for (int pass = 1; pass < npass; ++pass) run_pass(X3Int<0>{}, pass);
 
-    // ---- log-softmax denominators: the two column halves (wn) of every row
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // every logits store of the workgroup has left its wave; s_part complete
-    if (tid < 128) {
-        const float m0 = s_part[tid * 2], s0 = s_part[tid * 2 + 1];
-        const float m1 = s_part[(128 + tid) * 2], s1 = s_part[(128 + tid) * 2 + 1];
-        const float M = fmaxf(m0, m1);
-        const float S = s0 * __builtin_amdgcn_exp2f((m0 - M) * RNNT_LOG2E) + s1 * __builtin_amdgcn_exp2f((m1 - M) * RNNT_LOG2E);
-        s_den[tid] = M + __logf(S);
-    }
-    __syncthreads();
-    // thread = (row = tid & 127, which = tid >> 7): logit[blank] / logit[label] of the row, read through L2 (agent-scope
-    // loads bypass the CU's vector L1; the stores above are complete: vmcnt(0) + barrier)
-    {
-        const int row = tid & 127, which = tid >> 7;
-        const long cell = row0 + row;
-        if (cell < cells) {
-            const int u = (int)(cell % U1);
-            const long bt = cell / U1;
-            const int t = (int)(bt % T), b = (int)(bt / T);
-            const int Ub = len_u(a.target_lens, b, U1);
-            if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
-                const float den = s_den[row];
-                const float *lrow = a.logits + cell * V;
-                const long si = skew_index(b, t, u, a.D, U1);
-                if (which == 0) {
-                    const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.denom_s[si] = den;
-                    a.lpb_s[si] = lb - den;
-                } else {
-                    float le = 0.f;
-                    if (u < Ub) {
-                        const int y = a.targets[(long)b * (U1 - 1) + u];
-                        le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+        // ---- log-softmax denominators: the two column halves (wn) of every row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every logits / hidden store of the workgroup has left its wave; s_part complete
+        if (tid < 128) {
+            const float m0 = s_part[tid * 2], s0 = s_part[tid * 2 + 1];
+            const float m1 = s_part[(128 + tid) * 2], s1 = s_part[(128 + tid) * 2 + 1];
+            const float M = fmaxf(m0, m1);
+            const float S_ = s0 * __builtin_amdgcn_exp2f((m0 - M) * RNNT_LOG2E) + s1 * __builtin_amdgcn_exp2f((m1 - M) * RNNT_LOG2E);
+            s_den[tid] = M + __logf(S_);
+        }
+        __syncthreads();
+        // thread = (row = tid & 127, which = tid >> 7): logit[blank] / logit[label] of the row, read through L2
+        // (agent-scope loads bypass the CU's vector L1; the stores above are complete: vmcnt(0) + barrier)
+        {
+            const int row = tid & 127, which = tid >> 7;
+            const long cell = row0 + row;
+            if (cell < cells) {
+                const int u = (int)(cell % U1);
+                const long bt = cell / U1;
+                const int t = (int)(bt % T), b = (int)(bt / T);
+                const int Ub = len_u(a.target_lens, b, U1);
+                if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
+                    const float den = s_den[row];
+                    const float *lrow = a.logits + cell * V;
+                    const long si = skew_index(b, t, u, a.D, U1);
+                    if (which == 0) {
+                        const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.denom_s[si] = den;
+                        a.lpb_s[si] = lb - den;
+                    } else {
+                        float le = 0.f;
+                        if (u < Ub) {
+                            const int y = a.targets[(long)b * (U1 - 1) + u];
+                            le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                        }
+                        a.lpe_s[si] = le;
                     }
-                    a.lpe_s[si] = le;
                 }
             }
         }
+        tile = next;
     }
 }
 
@@ -780,12 +834,16 @@ void launch_joint_fwd_x3(const X3Args &a, hipStream_t st)
     static bool attr_set[16] = {false};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-    const int lds = 2 * XF_WSLOT + 2 * XF_ASLOT + 128 * 4 + 2 * 128 * 2 * 4;
+    const int lds = 2 * XF_WSLOT + 2 * XF_ASLOT + 128 * 4 + 2 * 128 * 2 * 4 + 16;
     if (dev < 0 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)k_joint_fwd_x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (dev >= 0) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_joint_fwd_x3, dim3((unsigned)(a.rows_alloc / 128)), dim3(256), lds, st, a);
+    const long cells = (long)a.B * a.T * a.U1;
+    const int ntiles = (int)((cells + 127) / 128);
+    launch_fill32(a.counter, 0u, 4, st);  // tile counter of the persistent workgroups
+    const int nwg = ntiles < a.n_cu ? ntiles : a.n_cu;  // one workgroup per CU (120 KiB of LDS each)
+    hipLaunchKernelGGL(k_joint_fwd_x3, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
 }
 
 // ---------------------------------------------------------------------------------------
