@@ -200,10 +200,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)   # >= 5 warm-ups, median of >= 20
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16x3"],
-                    help="fp32 = exact fp32 MFMA; bf16x3 = fp32-ACCURATE results from six bf16 MFMA products of "
-                         "3-way split operands (RNNT_DTYPE_F32_BF16X3, same 1e-4 parity bar); "
-                         "bf16 = BASELINE config 3's arithmetic (bf16 GEMM operands, fp32 accumulate)")
+    ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3"],
+                    help="bf16x3 (default) = fp32-ACCURATE results from six bf16 MFMA products of 3-way split operands "
+                         "(RNNT_DTYPE_F32_BF16X3: the fp32 route's 1e-4 parity bar, every fp32 parity test runs on it); "
+                         "fp32 = exact fp32 products on v_mfma_f32_32x32x2_f32 (1/16 of the bf16 matrix rate); "
+                         "bf16 = BASELINE config 3's arithmetic (bf16-rounded GEMM operands, fp32 accumulate)")
     ap.add_argument("--permuted-enc", action="store_true",
                     help="hand `enc` over as the reference does: the permute(0,2,1) view of an (N,C,L) tensor "
                          "(rnnt/model.py:27-28); the engine's tiled transpose is then part of every step")
@@ -344,7 +345,9 @@ def main():
         "arith": {"fp32": "v_mfma_f32_32x32x2_f32 (exact fp32 products)",
                   "bf16x3": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (operands split hi+mid+lo), fp32 accumulate",
                   "bf16": "v_mfma_f32_32x32x16_bf16 on bf16-rounded operands, fp32 accumulate, fp16 logits"}[args.dtype],
-        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} {args.dtype} joint+loss fwd+bwd" +
+        "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} " +
+                               {"fp32": "fp32", "bf16": "bf16", "bf16x3": "fp32-accurate (bf16x3 arithmetic)"}[args.dtype] +
+                               " joint+loss fwd+bwd" +
                                (", enc = permuted (N,C,L) view" if args.permuted_enc else ""),
                    "enc_layout": "permute(0,2,1) view of (N,C,L), as rnnt/model.py:27-28" if args.permuted_enc else "contiguous (B,T,H)",
                    "global_batch": B, "per_gpu_batch": Bl, "parallelism": f"dp{world}",
