@@ -286,7 +286,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
         h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags; h.n_ublk16 = (U1 + 15) / 16;
         h.dw_tab = (long *)(ws + L.counters + 1024);
-        h.counter = (unsigned *)(ws + L.counters + 512); h.n_cu = device_cus();
+        h.counter = (unsigned *)(ws + L.counters + 512); h.n_cu = device_cus(); h.debug = g_debug;
         const bool f32_dh = (xflags & RNNT_VARIANT_X3_FP32_DH) != 0 || !x3_dhidden_ok(U1, H, V);
         const bool f32_fwd = (xflags & RNNT_VARIANT_X3_FP32_FWD) != 0 || !x3_fwd_ok(U1, H, V) || f32_dh;  // fp32 dHidden reads fp32 hidden
         if ((f32_fwd || f32_dh) && ws_bytes < L.total + L.aux_bytes)

@@ -145,6 +145,7 @@ struct X3Args {
     long *dw_tab;        // 2B+2 longs: live-row table of k_dw_x3 (k_dw_table, 32-cell granules)
     unsigned *counter;   // zeroable word: tile counter of the persistent forward
     int n_cu;
+    unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
 };
 bool x3_fwd_ok(int U1, int H, int V);      // the bf16x3 forward kernel covers this shape (else: the fp32 route's)
 bool x3_dhidden_ok(int U1, int H, int V);  // likewise k_dhidden_x3

@@ -468,6 +468,7 @@ void launch_dw_x3(const X3Args &a, hipStream_t st)
 #define X3_EXP 0
 #endif
 #define X3_OFF(bit) ((X3_EXP) & (bit))
+#define XG_WAIT8_BUT(b, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
 #define XG_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
 // ---------------------------------------------------------------------------------------
 // W for the forward product, fragment order, three planes:
@@ -513,6 +514,23 @@ size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
 // ---------------------------------------------------------------------------------------
 #define XF_WSLOT 49152
 #define XF_ASLOT 12288
+#ifdef RNNT_STAMPS
+// Diagnostic build only (-DRNNT_STAMPS): s_memtime stamps of workgroup 0, wave XS_WAVE, k-steps 8..23 of its first tile:
+// debug[(step-8)*8 + slot]
+#ifndef XS_WAVE
+#define XS_WAVE 0
+#endif
+#define XSTAMP(slot)                                                                                        \
+    do {                                                                                                    \
+        if (a.debug && blockIdx.x == 0 && wave == XS_WAVE && lane == 0 && it == 1 && cs >= 8 && cs < 24) {   \
+            unsigned long long t_;                                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+            a.debug[(cs - 8) * 8 + (slot)] = t_;                                                            \
+        }                                                                                                   \
+    } while (0)
+#else
+#define XSTAMP(slot) do {} while (0)
+#endif
 __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int ntiles)
 {
     // [0, 96 KiB): W ring;  [96, 120 KiB): A ring;  then: s_den[128], s_part[2][128][2], s_next[2]
@@ -572,8 +590,9 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
         const int pt = (int)(pbt % T), pb = (int)(pbt / T);
         const float *ep = a.enc + (long)pb * a.enc_sb + (long)pt * a.enc_st + 8 * half;
         const float *pp = a.pred + ((long)pb * U1 + pu) * H + 8 * half;
-        const bool prow_ok = prow < cells;
-        u32x4 *hdst = (u32x4 *)a.hidden + prow * (H / 8) + half;  // + 2c: this lane's 16 bytes of k-step c; planes `ps` apart
+        // (rows past the lattice produce — and store, unconditionally — the last cell's row again: the same bits to the
+        // same place; hipcc counts vmcnt exactly only through unconditional memory operations)
+        u32x4 *hdst = (u32x4 *)a.hidden + pc_ * (H / 8) + half;  // + 2c: this lane's 16 bytes of k-step c; planes `ps` apart
         const long ps = a.plane_stride / 8;
         struct Opd { f32x4 e0, e1, p0, p1; };
         struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm, pl; };
@@ -616,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
             }
         };
         auto hid_store = [&](const Prod &P, int kcs) {
-            if (prow_ok && !X3_OFF(128)) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; hdst[2 * kcs + 2 * ps] = P.pl; }
+            if (!X3_OFF(128)) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; hdst[2 * kcs + 2 * ps] = P.pl; }
         };
         // piece n (0..11) of this wave's share of W k-step cs -> ring slot cs & 1
         auto wdma = [&](int cs, int n) {
@@ -651,13 +670,13 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
         };
         // pipeline prologue: W of k-step 0 by DMA; A of k-step 0 produced, stored, written to ring slot 0; operands of
         // k-step 1 requested
-        Opd onext;
+        Opd oset[2];  // operands of k-step cs+1 live in oset[(cs+1) & 1] during k-step cs (KC is even: the k loop is unrolled by 2)
         {
 #pragma unroll
             for (int n = 0; n < 12; ++n) wdma(0, n);
             Opd o; Prod P;
             op_load(o, 0);
-            op_load(onext, KC > 1 ? 1 : 0);
+            op_load(oset[1], KC > 1 ? 1 : 0);
 #pragma unroll
             for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, 0, pc);
             hid_store(P, 0);
@@ -672,18 +691,25 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
           // one k-step; STORE: first pass — the produced planes also go to memory.  Two straight-line instantiations
           // (hipcc counts vmcnt exactly only through straight-line code).
           constexpr bool STORE = decltype(store_c)::value != 0;
-          for (int kc = 0; kc < KC; ++kc, ++cs) {
+          for (int kc0 = 0; kc0 < KC; kc0 += 2)
+#pragma unroll
+          for (int par = 0; par < 2; ++par, ++cs) {
+            const int kc = kc0 + par;
             // W of k-step cs landed (this wave's share).  vmcnt retires in order: behind a k-step's DMAs come only its
             // 4 operand loads and (first pass) 3 hidden stores, which stay in flight; the first k-step of a pass also
             // follows the previous pass's logits stores
+            XSTAMP(0);
             if (kc == 0 || X3_OFF(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (STORE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            XSTAMP(1);
             x3_lds_barrier();  // publishes W slot and A slot of k-step cs; every wave is past its reads of cs-1
+            XSTAMP(2);
             const int ws = wb + (cs & 1) * XF_WSLOT, xs = xa + (cs & 1) * XF_ASLOT;
             // the next k-step (past the end: its own, never read) and the one after (operand loads)
             const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
-            Opd ocur = onext;  // operands of k-step cs+1 (requested during the previous k-step)
+            const Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
+            Opd &onext = oset[par & 1];             // refilled with those of k-step cs+2
             Prod P;
             u32x4 af[2][3], bf[8], bn[8];
 #pragma unroll
@@ -712,16 +738,21 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{}, X3Int<-1>{});   // ah.bh + DMA 0-7
-            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<8>{}, X3Int<-1>{});    // am.bh + reads of W mid, DMA 8-11
-            XG_WAIT8(bn);
+            // every fragment read is issued at least a block (16 MFMAs) before the wait that covers it
+            XSTAMP(3);
+            block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<-1>{});    // ah.bh + reads of W mid, DMA 0-7
+            block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // am.bh + DMA 8-11
+            XSTAMP(4);
             op_load(onext, kcnn);  // operands of k-step cs+2: behind the DMAs (they are needed a whole k-step from now)
             block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<0>{});   // al.bh + A(cs+1): tanh pieces
-            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<8>{});    // ah.bm + reads of W lo, A(cs+1): split pieces
-            XG_WAIT8(bf);
+            XG_WAIT8(bn);
+            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<8>{});    // ah.bm + reads of W lo (into the hi registers), A(cs+1): split pieces
+            XSTAMP(5);
             block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<16>{});  // am.bm + A(cs+1): ring writes
-            if (STORE && kc + 1 < KC) hid_store(P, kc + 1);                    // (the youngest memory operations of the k-step)
+            if (STORE) hid_store(P, kcn);  // (the youngest memory operations of the k-step; the pass's last k-step re-stores k-step 0)
+            XG_WAIT8_BUT(bf, 3);           // the three ring writes above may still fly
             block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+            XSTAMP(6);
             (void)kcn;
           }
           // pass complete: store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column groups exist
@@ -1100,18 +1131,19 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            block(X3Int<0>{}, bf, bn, X3Int<-1>{}, X3Int<0>{}, X3Int<0>{});    // ah.bh + DMA 0-3, G slices 0-7 (exp2, corrections, split)
-            block(X3Int<1>{}, bf, bn, X3Int<1>{}, X3Int<4>{}, X3Int<8>{});     // am.bh + reads of W mid, DMA 4-7, G slice 8 (exchange)
-            XG_WAIT8(bn);
+            // every fragment read is issued at least a block (16 MFMAs) before the wait that covers it
+            block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<0>{});     // ah.bh + reads of W mid, DMA 0-3, G slices 0-7 (exp2, corrections, split)
+            block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<4>{}, X3Int<8>{});    // am.bh + DMA 4-7, G slice 8 (exchange)
             block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // al.bh + DMA 8-11
             // G's stores and the raw ring refill come AFTER the k-step's DMAs: vmcnt retires in order, and the next
             // k-step's wait for the DMAs must not also wait out a store acknowledgement or an HBM load (needed 4
             // k-steps from now); they get one more k-step
             if (prod_on) produce_slice(P, rawn, c + 1, 9);
             if (!X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5);
+            XG_WAIT8(bn);
             block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
-            XG_WAIT8(bf);
             block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // am.bm
+            XG_WAIT8(bf);
             block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
         }
     }
