@@ -931,6 +931,18 @@ size_t x3_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V /
 #define XG_BU 16
 #define XG_WSLOT 49152   // one k-step of W: 3 planes x 16 tiles x 1 KiB
 #define XG_XSLOT 12288   // one k-step of G fragments: 4 M tiles x 3 planes x 1 KiB
+#ifdef RNNT_STAMPS
+#define GXSTAMP(slot)                                                                                                  \
+    do {                                                                                                               \
+        if (FIRST && a.debug && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == XS_WAVE && lane == 0 && c >= 8 && c < 24) { \
+            unsigned long long t_;                                                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                  \
+            a.debug[(c - 8) * 8 + (slot)] = t_;                                                                        \
+        }                                                                                                              \
+    } while (0)
+#else
+#define GXSTAMP(slot) do {} while (0)
+#endif
 template <bool FIRST>
 __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
 {
@@ -1055,9 +1067,14 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(P.pl) : "memory");
         }
         if (sl == 9 && FIRST && pexists && !X3_OFF(2)) {
-            gdst[8 * (c >> 1) + 2 * (c & 1)] = P.ph;
-            gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = P.pm;
-            ldst[2 * c] = P.pl;
+            if (X3_OFF(256)) {  // experiment: the same three stores, all to one cache-resident kilobyte (NOT a valid build)
+                u32x4 *dump = (u32x4 *)(a.g_lo + zrow * V) + lane;
+                dump[0] = P.ph; dump[64] = P.pm; dump[128] = P.pl;
+            } else {
+                gdst[8 * (c >> 1) + 2 * (c & 1)] = P.ph;
+                gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = P.pm;
+                ldst[2 * c] = P.pl;
+            }
         }
     };
     auto produce = [&](const Raw &r, int c) {  // all slices at once (pipeline prologue)
@@ -1089,11 +1106,14 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             // (vmcnt retires in order: all but the G stores and raw-ring loads issued behind the previous k-step's
             // DMAs.  In-place safety: a store of k-step s's G overwrites logits bytes of k-steps <= s+1, every one of
             // them loaded — and waited for by this counter — at least two k-steps before the store is issued.)
+            GXSTAMP(0);
             if (X3_OFF(4) || X3_OFF(2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (FIRST && wave_stores) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // 3 G stores + 2 raw loads behind the DMAs
             else if (FIRST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // a wave without an existing cell issues no store
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            GXSTAMP(1);
             x3_lds_barrier();
+            GXSTAMP(2);
             const int ws = wb + (j & 1) * XG_WSLOT, xs = xa + (j & 1) * XG_XSLOT;
             u32x4 af[2][3], bf[8], bn[8];
             // fragment reads: A (6) and the hi plane of W (8)
@@ -1132,8 +1152,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                 }
             };
             // every fragment read is issued at least a block (16 MFMAs) before the wait that covers it
+            GXSTAMP(3);
             block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<0>{});     // ah.bh + reads of W mid, DMA 0-3, G slices 0-7 (exp2, corrections, split)
             block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<4>{}, X3Int<8>{});    // am.bh + DMA 4-7, G slice 8 (exchange)
+            GXSTAMP(4);
             block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // al.bh + DMA 8-11
             // G's stores and the raw ring refill come AFTER the k-step's DMAs: vmcnt retires in order, and the next
             // k-step's wait for the DMAs must not also wait out a store acknowledgement or an HBM load (needed 4
@@ -1142,9 +1164,11 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             if (!X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5);
             XG_WAIT8(bn);
             block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
+            GXSTAMP(5);
             block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // am.bm
             XG_WAIT8(bf);
             block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+            GXSTAMP(6);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued ring loads / DMAs

@@ -13,13 +13,16 @@ for s in range(8): run(s)
 torch.cuda.synchronize()
 dbg = torch.zeros(16 * 8, dtype=torch.int64, device="cuda")
 engine.lib().rnnt_engine_set_debug(ctypes.c_void_p(dbg.data_ptr()))
-run(1); torch.cuda.synchronize()
+STAGE = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # 1: k_joint_fwd_x3, 4: k_dhidden_x3
+run(STAGE); torch.cuda.synchronize()
 engine.lib().rnnt_engine_set_debug(ctypes.c_void_p(0))
 d = dbg.cpu().numpy().reshape(16, 8)
 names = ["vmcnt wait", "barrier", "reads issue+land", "blocks 0-1", "block 2 (+loads)", "block 3", "blocks 4-5 (+stores)"]
 seg = np.diff(d[:, :7], axis=1)
 print(os.path.basename(os.environ.get("RNNT_ENGINE_LIB", "")))
-for i, n in enumerate(["0->1 vmcnt wait", "1->2 barrier", "2->3 first reads land", "3->4 blocks 0,1", "4->5 blocks 2,3", "5->6 blocks 4,5"]):
+labels = ["0->1 vmcnt wait", "1->2 barrier", "2->3 first reads land", "3->4 blocks 0,1", "4->5 blocks 2,3", "5->6 blocks 4,5"] if STAGE == 1 else \
+         ["0->1 vmcnt wait", "1->2 barrier", "2->3 first reads land", "3->4 blocks 0,1", "4->5 block 2, stores, loads, block 3", "5->6 blocks 4,5"]
+for i, n in enumerate(labels):
     print(f"  {n:24s} median {np.median(seg[:, i]):7.0f}  min {seg[:, i].min():6d} max {seg[:, i].max():6d}")
 step = np.diff(d[:, 0])
 print("  k-step period (stamp 0 to next stamp 0): median", np.median(step), " -> ideal 96 MFMAs x 32 = 3072")
