@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
             // 4 operand loads and (first pass) 3 hidden stores, which stay in flight; the first k-step of a pass also
             // follows the previous pass's logits stores
             XSTAMP(0);
-            if (kc == 0 || X3_OFF(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (X3_OFF(512)) {}  // experiment: no wait at all (NOT a valid build)
+            else if (kc == 0 || X3_OFF(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (STORE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             XSTAMP(1);
@@ -1107,7 +1108,8 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             // DMAs.  In-place safety: a store of k-step s's G overwrites logits bytes of k-steps <= s+1, every one of
             // them loaded — and waited for by this counter — at least two k-steps before the store is issued.)
             GXSTAMP(0);
-            if (X3_OFF(4) || X3_OFF(2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (X3_OFF(512)) {}  // experiment: no wait at all (NOT a valid build: the W ring may be read before it landed)
+            else if (X3_OFF(4) || X3_OFF(2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (FIRST && wave_stores) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // 3 G stores + 2 raw loads behind the DMAs
             else if (FIRST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // a wave without an existing cell issues no store
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");

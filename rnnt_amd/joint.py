@@ -47,9 +47,15 @@ class JointNetwork(torch.nn.Module):
         audio_frame, text_frame = self._project(audio_frame, text_frame)
         return F_amd.joint_logits(audio_frame, text_frame, self.joint_ln.weight, self.joint_ln.bias)
 
+    # Arithmetic of the fused training step (RNNTModel.forward): "bf16x3" = fp32-ACCURATE results from the bf16 matrix
+    # pipes (include/rnnt_engine.h RNNT_DTYPE_F32_BF16X3: the fp32 route's 1e-4 parity bar, ~1.5x its speed); "fp32" =
+    # exact fp32 products; "bf16" = bf16-rounded operands (BASELINE config 3; not the reference's arithmetic).
+    compute_dtype = "bf16x3"
+
     def fused_loss(self, audio_frame, text_frame, targets, logit_lengths, target_lengths,
                    blank=-1, reduction="mean", **kw):
         """joint + transducer loss in one engine call (reference model.py:32-41)."""
+        kw.setdefault("dtype", self.compute_dtype)
         audio_frame, text_frame = self._project(audio_frame, text_frame)
         return F_amd.joint_rnnt_loss(audio_frame, text_frame, self.joint_ln.weight,
                                      self.joint_ln.bias, targets, logit_lengths, target_lengths,
