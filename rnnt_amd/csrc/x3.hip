@@ -1015,12 +1015,13 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     const u32x4 *wsrc = (const u32x4 *)a.wpack_dh + (long)hp * VC * 3072 + (wave * 12) * 64 + lane;
 
     struct Raw { f32x4 x0, x1; u32x4 l; };  // FIRST: 8 fp32 logits; else: hi | mid (as x0, x1 bits) and lo planes
-    auto xload = [&](Raw &r, int c) {
+    auto xload = [&](Raw &r, int c, int part = 3) {  // part: 1 first half, 2 second half, 3 both (FIRST)
         const int cc = c < VC ? c : VC - 1;
         if (FIRST) {
             const f32x4 *p = (const f32x4 *)xsrc + 4 * cc + 2 * half;
-            r.x0 = p[0]; r.x1 = p[1];
-        } else {
+            if (part & 1) r.x0 = p[0];
+            if (part & 2) r.x1 = p[1];
+        } else if (part & 1) {
             const u32x4 *p = (const u32x4 *)xsrc + 8 * (cc >> 1) + 2 * (cc & 1) + half;
             r.x0 = __builtin_bit_cast(f32x4, p[0]); r.x1 = __builtin_bit_cast(f32x4, p[4]);
             r.l = lsrc[2 * cc];
@@ -1067,21 +1068,21 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
             asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(P.pl) : "memory");
         }
-        if (sl == 9 && FIRST && pexists && !X3_OFF(2)) {
+        if (sl >= 9 && sl <= 11 && FIRST && pexists && !X3_OFF(2)) {  // the three stores, one slice each
             if (X3_OFF(256)) {  // experiment: the same three stores, all to one cache-resident kilobyte (NOT a valid build)
                 u32x4 *dump = (u32x4 *)(a.g_lo + zrow * V) + lane;
-                dump[0] = P.ph; dump[64] = P.pm; dump[128] = P.pl;
+                if (sl == 9) dump[0] = P.ph; else if (sl == 10) dump[64] = P.pm; else dump[128] = P.pl;
             } else {
-                gdst[8 * (c >> 1) + 2 * (c & 1)] = P.ph;
-                gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = P.pm;
-                ldst[2 * c] = P.pl;
+                if (sl == 9) gdst[8 * (c >> 1) + 2 * (c & 1)] = P.ph;
+                else if (sl == 10) gdst[8 * (c >> 1) + 4 + 2 * (c & 1)] = P.pm;
+                else ldst[2 * c] = P.pl;
             }
         }
     };
     auto produce = [&](const Raw &r, int c) {  // all slices at once (pipeline prologue)
         Prod P;
 #pragma unroll
-        for (int sl = 0; sl < 10; ++sl) produce_slice(P, r, c, sl);
+        for (int sl = 0; sl < 12; ++sl) produce_slice(P, r, c, sl);
     };
     auto wdma = [&](int c, int n) {  // piece n (0..11) of this wave's share of W k-step c -> ring slot c & 1
         const int cc = c < VC ? c : VC - 1;
@@ -1138,8 +1139,11 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             Prod P;
             const bool prod_on = c + 1 < VC;  // workgroup-uniform
             const Raw &rawn = xr[(j + 1) & 3];
-            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto s0_c) {
+            // MEM: the k-step's five HBM operations, spread one per half block behind the DMAs (0: none; 1: G hi + mid
+            // stores; 2: G lo store + first logits load; 3: second logits load)
+            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto s0_c, auto mem_c) {
                 constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value, S0 = decltype(s0_c)::value;
+                constexpr int MEM = decltype(mem_c)::value;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (!X3_OFF(1)) {
@@ -1150,26 +1154,29 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
                     if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
                     if (S0 >= 0 && S0 + q < 9 && prod_on && !(X3_OFF(32) && S0 + q < 8)) produce_slice(P, rawn, c + 1, (S0 < 0 ? 0 : S0) + q);
+                    if (MEM == 1 && q == 1 && prod_on) produce_slice(P, rawn, c + 1, 9);
+                    if (MEM == 1 && q == 5 && prod_on) produce_slice(P, rawn, c + 1, 10);
+                    if (MEM == 2 && q == 1 && prod_on) produce_slice(P, rawn, c + 1, 11);
+                    if (MEM == 2 && q == 5 && !X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5, 1);
+                    if (MEM == 3 && q == 1 && !X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5, 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             // every fragment read is issued at least a block (16 MFMAs) before the wait that covers it
             GXSTAMP(3);
-            block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<0>{});     // ah.bh + reads of W mid, DMA 0-3, G slices 0-7 (exp2, corrections, split)
-            block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<4>{}, X3Int<8>{});    // am.bh + DMA 4-7, G slice 8 (exchange)
+            block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<0>{}, X3Int<0>{});     // ah.bh + reads of W mid, DMA 0-3, G slices 0-7 (exp2, corrections, split)
+            block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<4>{}, X3Int<8>{}, X3Int<0>{});    // am.bh + DMA 4-7, G slice 8 (exchange)
             GXSTAMP(4);
-            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // al.bh + DMA 8-11
-            // G's stores and the raw ring refill come AFTER the k-step's DMAs: vmcnt retires in order, and the next
-            // k-step's wait for the DMAs must not also wait out a store acknowledgement or an HBM load (needed 4
-            // k-steps from now); they get one more k-step
-            if (prod_on) produce_slice(P, rawn, c + 1, 9);
-            if (!X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5);
+            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{}, X3Int<0>{});   // al.bh + DMA 8-11
+            // G's stores and the raw ring refill come AFTER the k-step's DMAs (vmcnt retires in order: the next k-step's
+            // wait for the DMAs must not also wait out a store acknowledgement or an HBM load needed 4 k-steps from
+            // now), one per half block: five back-to-back HBM operations fill the CU's memory queue and block the wave
             XG_WAIT8(bn);
-            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<-1>{});   // ah.bm + reads of W lo (into the hi registers)
+            block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<-1>{}, X3Int<1>{});   // ah.bm + reads of W lo (into the hi registers); G hi, mid stores
             GXSTAMP(5);
-            block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // am.bm
+            block(X3Int<1>{}, bn, bn, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{}, X3Int<2>{});  // am.bm; G lo store, logits load
             XG_WAIT8(bf);
-            block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{});  // ah.bl
+            block(X3Int<0>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<-1>{}, X3Int<3>{});  // ah.bl; logits load
             GXSTAMP(6);
         }
     }
