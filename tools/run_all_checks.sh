@@ -24,7 +24,7 @@ run() {  # run <name> <timeout s> <cmd...>
 S1=${SEED1:-$RANDOM}; S2=${SEED2:-$RANDOM}; S3=${SEED3:-$RANDOM}; S4=${SEED4:-$RANDOM}; S5=${SEED5:-$RANDOM}
 echo "seeds: fuzz_parity=$S1 fuzz_lattice=$S2 fuzz_misc=$S3 fuzz_blank=$S4 fuzz_pad=$S5 (replay: SEED1=.. SEED5=.. bash tools/run_all_checks.sh)"
 run pytest_gpu 900 python3 -m pytest tests -q -x -m gpu
-run fuzz_parity 600 python3 tools/fuzz_parity.py 150 60 "$S1" 400 100
+run fuzz_parity 900 python3 tools/fuzz_parity.py 150 60 "$S1" 400 100 120
 run fuzz_lattice 300 python3 tools/fuzz_lattice.py 40 20 "$S2"
 run fuzz_misc 300 python3 tools/fuzz_misc.py 30 "$S3"
 run fuzz_blank 300 python3 tools/fuzz_blank.py 60 "$S4"
