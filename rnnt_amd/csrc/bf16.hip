@@ -34,6 +34,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i16x4 *lds_i16x4_ptr;
+typedef __attribute__((address_space(3))) void *lds_vptr;
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 {
@@ -165,15 +168,14 @@ __global__ __launch_bounds__(256) void k_pack_w_dh_bf16(const float *__restrict_
 size_t bf16_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 255) / 256) * (H / 32) * 2 * 8 * 64 * 16; }
 size_t bf16_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V / 32) * 2 * 16 * 64 * 16; }
 
+static void launch_pack_w_fwd_bf16(const Bf16Args &a, hipStream_t st);  // the layout the chosen forward kernel reads
 void launch_bf16_producers(const Bf16Args &a, hipStream_t st)
 {
     // hidden is produced by the forward kernel's tiles; only the zero padding rows past the last cell
     // (the dW DMA ring walks them) are written here
     const long cells = (long)a.B * a.T * a.U1;
     launch_fill32(a.hidden + cells * a.H, 0u, (size_t)(a.rows_alloc - cells) * a.H * 2, st);
-    const long nf = (long)(bf16_wpack_fwd_bytes(a.H, a.V) / 16);
-    hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W,
-                       (u32x4 *)a.wpack_fwd, a.H, a.V, a.H / 32, nf);
+    launch_pack_w_fwd_bf16(a, st);
     const long nd = (long)(bf16_wpack_dh_bytes(a.H, a.V) / 16);
     hipLaunchKernelGGL(k_pack_w_dh_bf16, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a.W,
                        (u32x4 *)a.wpack_dh, a.H, a.V, nd);
@@ -403,9 +405,439 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_joint_fwd_bf16_ra<KC>: the forward for H = 64*KC with the tile's hidden rows held in REGISTERS (round 3).
+// The kernel above re-fetches a tile's hidden rows on every column pass (V/256 times; counted: 2.9x the
+// algorithmic traffic) and stages W through VGPRs.  Here a wave produces the hidden rows of its 32 cells straight
+// into MFMA fragment registers (KC x 4 fragments of 16 B: H/4 registers per lane), stores them once for
+// k_dw_bf16, and keeps them for all column passes: no hidden read at all, no HBM round trip between production
+// and the products, and the only memory stream of the main loop is W by LDS-DMA.
+//  * workgroup = 4 waves x 32 cells = 128 consecutive cells; two workgroups per CU up to H = 512 (128 fragment
+//    registers + 64 accumulators per wave), one at H = 1024;
+//  * the product is TRANSPOSED: logits^T tile = W tile (A operand, 32 vocabulary rows, from LDS) x hidden^T (B
+//    operand, the wave's 32 cells, from registers), so a lane owns ONE cell (column l&31) and 16 vocabulary entries
+//    per accumulator tile: the log-softmax statistics are lane-local (a running max and sum per lane, the two
+//    halves of the wave combined once per tile) — no cross-lane reduction, no LDS exchange in the pass epilogue;
+//  * k permutation: chunk c (64 deep), MFMA s (0..3), lane (r, h), element e  <->  k = 64c + 32h + 8s + e: a lane
+//    owns 32 consecutive k of its cell per chunk;
+//  * pass = 128 logits columns = 4 accumulator tiles; W row rho of tile t = column 128*pass + 32*(rho>>3) +
+//    16*((rho>>2)&1) + 4t + (rho&3), so accumulator register 4g+i of tile t in lane (j, half) is column
+//    128*pass + 32g + 16*half + 4t + i of cell j: per g a lane holds 16 adjacent logits (32 bytes) of its row and the
+//    wave 64 contiguous bytes of each of its 32 rows.  Stored per lane these are 64 cache lines per instruction
+//    (measured: the stores then clog the memory pipe, +1.9 ms); they go through 2 KiB of wave-private LDS instead
+//    and leave row-major, 16 rows x 64 contiguous bytes per instruction;
+//    W chunk (pass, c) = 16 fragments [s][tile][lane] x 16 B = 16 KiB, 4-slot LDS ring filled by raw-buffer LDS-DMA
+//    (4 per wave and chunk).  The barrier at the top of chunk n publishes chunk n+1, so the first fragment group
+//    of a chunk is requested before the barrier that precedes it;
+//  * bias: the accumulators start at zero (first MFMA of a pass takes C = 0) and the pass epilogue adds the
+//    pass's 128 bias values from a double-buffered LDS table (broadcast reads).
+// Requires V % 128 == 0.  Same rounding points as the kernel above (bf16 operands, fp32 accumulation, fp16 logits,
+// statistics from the stored values); the k order inside an accumulator differs.
+// ---------------------------------------------------------------------------------------
+// Diagnostic builds only (-DFR_EXP=bits, tools/build_bf16_variants.sh): parts of k_joint_fwd_bf16_ra compiled out —
+// 1 no MFMAs, 2 no statistics, 4 no logits stores, 8 no hidden stores, 16 no W DMA, 32 no tanh,
+// 64 one workgroup per CU (100 KiB of LDS requested)
+#ifndef FR_EXP
+#define FR_EXP 0
+#endif
+#define FR_OFF(bit) ((FR_EXP) & (bit))
+#ifdef RNNT_STAMPS
+// Diagnostic build only (-DRNNT_STAMPS): s_memtime stamps of workgroup FRS_BLOCK, every wave: debug[wave*128 + slot]
+#ifndef FRS_BLOCK
+#define FRS_BLOCK 20000
+#endif
+#define FRSTAMP(slot)                                                                       \
+    do {                                                                                    \
+        if (a.debug && blockIdx.x == FRS_BLOCK && lane == 0) {                              \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            a.debug[wave * 128 + (slot)] = t_;                                              \
+        }                                                                                   \
+    } while (0)
+#else
+#define FRSTAMP(slot) do {} while (0)
+#endif
+#define FR_SLOT 16384
+template <int N> struct BInt { static constexpr int value = N; };
+
+// W in the order k_joint_fwd_bf16_ra consumes it: [pass][c][s][tile(4)][lane] x 8 bf16, element e =
+// W[v = 128*pass + 32*(rho>>3) + 16*((rho>>2)&1) + 4*tile + (rho&3)][h = 64c + 32*(lane>>5) + 8s + e], rho = lane&31
+__global__ __launch_bounds__(256) void k_pack_w_fwd_bf16_ra(const float *__restrict__ W, u32x4 *__restrict__ out, int H, long n)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 3, s = (int)(idx >> 8) & 3;
+    const long cc = idx >> 10;
+    const int KC = H / 64;
+    const int c = (int)(cc % KC), pass = (int)(cc / KC);
+    const int rho = lane & 31;
+    const int v = 128 * pass + 32 * (rho >> 3) + 16 * ((rho >> 2) & 1) + 4 * tile + (rho & 3);
+    const float *w = W + (long)v * H + 64 * c + 32 * (lane >> 5) + 8 * s;
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16(w[2 * j], w[2 * j + 1]);
+    out[idx] = o;
+}
+
+template <int KC>
+__global__ __launch_bounds__(256, (KC <= 8 ? 2 : 1)) void k_joint_fwd_bf16_ra(Bf16Args a)
+{
+    // [0, 64 KiB): W ring, 4 slots (slot 3 doubles as the production's transposition space);  then s_bias[2][128];
+    // then the logits staging space, 2 KiB per wave
+    extern __shared__ __attribute__((aligned(1024))) char s_fr[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, half = lane >> 5;
+    constexpr int H = 64 * KC;
+    const int V = a.V, U1 = a.U1, T = a.T;
+    const int npass = V / 128;
+    const int NC = npass * KC;
+    const long cells = (long)a.B * T * U1, per = (long)T * U1;
+    const long c_first = (long)blockIdx.x * 128;
+    if (c_first >= cells) return;
+    // a tile entirely in the dead time steps (t >= T_b) of one utterance: hidden only (finite rows for k_dw_bf16);
+    // its logits are never read (k_dhidden_bf16 zero-fills the G rows of dead tiles itself)
+    bool dead;
+    {
+        const long c_last = c_first + 127, b_first = c_first / per;
+        dead = c_last < cells && c_last / per == b_first && (c_first - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T);
+    }
+    const long row0 = c_first + wave * 32;
+    FRSTAMP(0);
+    const int lds0 = (int)(size_t)(lds_vptr)s_fr;
+    const int bias_w = lds0 + 4 * FR_SLOT + 16 * j;  // table write: lanes (j, .) hold columns 4j .. 4j+3 of a pass
+    {   // pass 0's bias (every wave writes the same 512 bytes)
+        const f32x4 bv = *(const f32x4 *)(a.bias + 4 * j);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(bias_w), "v"(bv) : "memory");
+    }
+
+    // ---- W ring: fragment 4*wave + q of chunk n -> slot n & 3
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, (int)((long)V * H * 2), 0x00020000);
+    const int wvo = wave * 4096 + lane * 16;
+    auto wdma = [&](int n, int q) {
+        if (FR_OFF(16)) return;
+        const int src = n < NC ? n : NC - 1;  // past the end: the last chunk again (landed, never read)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fr + (n & 3) * FR_SLOT + wave * 4096 + q * 1024), 16, wvo,
+                                                 src * FR_SLOT + q * 1024, 0, 0);
+    };
+    if (!dead) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wdma(n, q);
+    }
+    FRSTAMP(1);
+    asm volatile("" ::: "memory");  // the production's loads stay behind the DMAs: their data implies the DMAs landed
+
+    // ---- hidden = bf16(tanh(enc + pred)) of this lane's cell, in fragment order, kept in registers.
+    // Loads and stores are row-major (16 lanes cover 64 consecutive k of a row: whole 128-byte lines; a lane that read
+    // its own fragment slots instead touched 64 lines per instruction); the transposition into fragment order goes
+    // through 4 KiB of LDS per wave (ring slot 3, idle until the main loop): lane (sub = lane>>4, kq = lane&15)
+    // handles rows 4i + sub (i = 0..7), k = 64c + 4kq .. +3 of chunk c; 16-byte positions inside a row's 128 bytes are
+    // XORed with (row>>1)&7 (conflict-free ds_read_b128 of the fragments: row j, bytes 64*half + 16s).
+    u32x4 A[KC][4];
+    {
+        const int sub = lane >> 4, kq = lane & 15;
+        const long rowc = row0 < cells ? row0 : cells - 1;  // rows past the lattice: the last cell again (same bits, same place)
+        const int rmax = (int)(cells - 1 - rowc < 31 ? cells - 1 - rowc : 31);
+        const int u0 = (int)(rowc % U1);
+        const long bt0 = rowc / U1;
+        const int t0 = (int)(bt0 % T), b0 = (int)(bt0 / T);
+        unsigned eo[8], po[8];  // element offsets of this lane's 8 rows
+        const float *ebase = a.enc + (long)b0 * a.enc_sb + 4 * kq;
+        const float *pbase = a.pred + (long)b0 * U1 * H + 4 * kq;
+        unsigned short *hbase = a.hidden + rowc * H + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int r = 4 * i + sub;
+            r = r < rmax ? r : rmax;
+            int u = u0 + r, t = t0, db = 0;
+            while (u >= U1) { u -= U1; if (++t == T) { t = 0; ++db; } }
+            eo[i] = (unsigned)(db * a.enc_sb + (long)t * a.enc_st);
+            po[i] = (unsigned)((db * U1 + u) * H);
+        }
+        const int tbase = lds0 + 3 * FR_SLOT + wave * 4096;
+        const int trd = tbase + j * 128;  // fragment s: + ((4half + s) ^ ((j>>1)&7)) * 16
+        // operands of a half batch st (chunk st>>1, rows i = 4(st&1) .. +3): 4 + 4 vectors; three buffers, loads issued
+        // two half batches ahead of their use (the L2 round trip is longer than one half batch of arithmetic)
+        f32x4 lb[3][8];
+        auto ld = [&](f32x4 (&b)[8], int st) {
+            const int c = st >> 1, i0 = 4 * (st & 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                b[k] = *(const f32x4 *)(ebase + eo[i0 + k] + 64 * c);
+                b[4 + k] = *(const f32x4 *)(pbase + po[i0 + k] + 64 * c);
+            }
+        };
+        ld(lb[0], 0);
+        if (2 * KC > 1) ld(lb[1], 1);
+#pragma unroll
+        for (int st = 0; st < 2 * KC; ++st) {
+            if (st + 2 < 2 * KC) ld(lb[(st + 2) % 3], st + 2);
+            const f32x4(&b)[8] = lb[st % 3];
+            const int c = st >> 1, i0 = 4 * (st & 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k;
+                const f32x4 tv = FR_OFF(32) ? b[k] + b[4 + k] : fast_tanh_sum4(b[k], b[4 + k]);
+                const u32x2 o = {pack_bf16(tv[0], tv[1]), pack_bf16(tv[2], tv[3])};
+                const int row = 4 * i + sub;
+                const int r = row < rmax ? row : rmax;
+                if (!FR_OFF(8)) *(u32x2 *)(hbase + (unsigned)(r * H) + 64 * c) = o;
+                const int wa = tbase + row * 128 + (((kq >> 1) ^ ((row >> 1) & 7)) << 4) + 8 * (kq & 1);
+                asm volatile("ds_write_b64 %0, %1" :: "v"(wa), "v"(o) : "memory");
+            }
+            if (st & 1) {
+                const int x = (j >> 1) & 7;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(A[c][0]), "=&v"(A[c][1]), "=&v"(A[c][2]), "=&v"(A[c][3])
+                             : "v"(trd + (((4 * half + 0) ^ x) << 4)), "v"(trd + (((4 * half + 1) ^ x) << 4)),
+                               "v"(trd + (((4 * half + 2) ^ x) << 4)), "v"(trd + (((4 * half + 3) ^ x) << 4))
+                             : "memory");
+            }
+        }
+    }
+    FRSTAMP(2);
+    if (dead) return;
+
+    const int rb = lds0 + lane * 16;  // fragment (s, tile) of slot k: rb + k*FR_SLOT + (4s + tile)*1024
+    float st_m = RNNT_NEG_INF, st_s = 0.f;  // running (max, sum exp) of this lane's cell over its 64 columns of every pass
+
+    f32x16 acc[4];
+    u32x4 g0[4], g1[4];
+    auto reads = [&](u32x4 (&g)[4], int base, auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g[0]) : "v"(base), "n"((4 * S + 0) * 1024));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g[1]) : "v"(base), "n"((4 * S + 1) * 1024));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g[2]) : "v"(base), "n"((4 * S + 2) * 1024));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g[3]) : "v"(base), "n"((4 * S + 3) * 1024));
+    };
+    auto landed = [&](u32x4 (&g)[4], bool wait) {
+        if (wait) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) :: "memory");
+        else asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
+    };
+    // 4 MFMAs: W fragments g (A operand: 32 vocabulary rows each) x this wave's cells (B operand, registers)
+    auto mma4 = [&](auto first_c, const u32x4 &hf, const u32x4 (&g)[4], int n, int q) {
+        constexpr bool FIRST = decltype(first_c)::value != 0;  // first k-step of a pass: C = 0
+        if (!FR_OFF(1)) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[0] = mfma_bf16(g[0], hf, FIRST ? z : acc[0]);
+            acc[1] = mfma_bf16(g[1], hf, FIRST ? z : acc[1]);
+        }
+        wdma(n + 3, q);
+        if (!FR_OFF(1)) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[2] = mfma_bf16(g[2], hf, FIRST ? z : acc[2]);
+            acc[3] = mfma_bf16(g[3], hf, FIRST ? z : acc[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (FR_OFF(1)) {
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
+    }
+
+    // chunks 0..2 have landed (the production consumed loads issued after their DMAs; stores may still fly)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * KC < 63 ? 8 * KC : 63) : "memory");
+    lds_barrier();
+    FRSTAMP(3);
+    reads(g0, rb, BInt<0>{});
+
+    // logits staging: lane (j, half) writes its 32 bytes of a g group to row j (64 bytes per row), 16-byte chunk
+    // 2*half + k at position chunk ^ ((j>>2)&3); lane l then reads chunk l&3 of rows (l>>2), 16 + (l>>2) and stores it
+    const int stg = lds0 + 4 * FR_SLOT + 1024 + wave * 2048;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int n0 = pass * KC;
+        FRSTAMP(4 + 3 * pass);
+        auto chunk = [&](auto c_c) {
+            constexpr int c = decltype(c_c)::value;
+            const int n = n0 + c;
+            // this wave's share of chunk n+1 has landed.  vmcnt retires in order; younger than those DMAs are the 4
+            // of chunk n+2 and, in the first two chunks of a pass, the 8 logits stores + the bias load of the epilogue
+            // (the first pass's chunks 1 and 2 landed before the loop: no wait behind the hidden stores)
+            if (c < 2) { if (pass != 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (pass == 3) FRSTAMP(64 + 3 * c);
+            lds_barrier();  // publishes chunk n+1; every wave is past its reads of chunk n-1 (slot of chunk n+3)
+            if (pass == 3) FRSTAMP(65 + 3 * c);
+            landed(g0, false);
+            const int sb = rb + ((n & 3) << 14), sbn = rb + (((n + 1) & 3) << 14);
+            reads(g1, sb, BInt<1>{});
+            mma4(BInt<(c == 0)>{}, A[c][0], g0, n, 0);
+            landed(g1, true);
+            reads(g0, sb, BInt<2>{});
+            mma4(BInt<0>{}, A[c][1], g1, n, 1);
+            landed(g0, true);
+            reads(g1, sb, BInt<3>{});
+            mma4(BInt<0>{}, A[c][2], g0, n, 2);
+            landed(g1, true);
+            reads(g0, sbn, BInt<0>{});  // first group of chunk n+1 (published above; past the end: an unused landed slot)
+            mma4(BInt<0>{}, A[c][3], g1, n, 3);
+            if (pass == 3) FRSTAMP(66 + 3 * c);
+        };
+        if constexpr (KC >= 1) chunk(BInt<0>{});
+        if constexpr (KC >= 2) chunk(BInt<1>{});
+        if constexpr (KC >= 3) chunk(BInt<2>{});
+        if constexpr (KC >= 4) chunk(BInt<3>{});
+        if constexpr (KC >= 5) chunk(BInt<4>{});
+        if constexpr (KC >= 6) chunk(BInt<5>{});
+        if constexpr (KC >= 7) chunk(BInt<6>{});
+        if constexpr (KC >= 8) chunk(BInt<7>{});
+        if constexpr (KC >= 9) chunk(BInt<8>{});
+        if constexpr (KC >= 10) chunk(BInt<9>{});
+        if constexpr (KC >= 11) chunk(BInt<10>{});
+        if constexpr (KC >= 12) chunk(BInt<11>{});
+        if constexpr (KC >= 13) chunk(BInt<12>{});
+        if constexpr (KC >= 14) chunk(BInt<13>{});
+        if constexpr (KC >= 15) chunk(BInt<14>{});
+        if constexpr (KC >= 16) chunk(BInt<15>{});
+
+        // ---- pass end: + bias, fp16 logits out (through the wave's staging space), statistics from the rounded values
+        FRSTAMP(5 + 3 * pass);
+        {
+            // the next pass's bias: requested here, written to the other half of the table at the end of this epilogue
+            const f32x4 bn = *(const f32x4 *)(a.bias + 128 * (pass + 1 < npass ? pass + 1 : pass) + 4 * j);
+            char *rowp = (char *)(a.logits + row0 * V + 128 * pass);  // wave-uniform
+            // per-lane addresses from a fresh lane id (not carried through the main loop: registers)
+            int ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            const int jj = ln & 31, hh = ln >> 5;
+            const int stw0 = stg + jj * 64 + (((2 * hh) ^ ((jj >> 2) & 3)) << 4), stw1 = stg + jj * 64 + (((2 * hh + 1) ^ ((jj >> 2) & 3)) << 4);
+            const int strd = stg + (ln >> 2) * 64 + (((ln & 3) ^ ((ln >> 4) & 3)) << 4);  // rows l>>2 and 16 + (l>>2): same XOR term
+            const unsigned lane_off = (unsigned)(((ln >> 2) * V + 8 * (ln & 3)) * 2);
+            const int bias_r = lds0 + 4 * FR_SLOT + (pass & 1) * 512 + 64 * hh;  // columns 32g + 16*half + 4t + i
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[t]) : "v"(bias_r), "n"(128 * g + 16 * t));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) :: "memory");
+                u32x4 q0, q1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float x0, x1, x2, x3;  // (volatile: the reads stay here, one group at a time)
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[t][4 * g + 0]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[t][4 * g + 1]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x2) : "a"(acc[t][4 * g + 2]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x3) : "a"(acc[t][4 * g + 3]));
+                    const unsigned lo = pack_f16(x0 + bq[t][0], x1 + bq[t][1]), hi = pack_f16(x2 + bq[t][2], x3 + bq[t][3]);
+                    if (t < 2) { q0[2 * t] = lo; q0[2 * t + 1] = hi; } else { q1[2 * (t - 2)] = lo; q1[2 * (t - 2) + 1] = hi; }
+                }
+                if (!FR_OFF(4)) asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3" :: "v"(stw0), "v"(stw1), "v"(q0), "v"(q1) : "memory");
+                if (!FR_OFF(2)) {
+                    const unsigned m4 = pk_max_f16(pk_max_f16(pk_max_f16(q0[0], q0[1]), pk_max_f16(q0[2], q0[3])),
+                                                   pk_max_f16(pk_max_f16(q1[0], q1[1]), pk_max_f16(q1[2], q1[3])));
+                    const float lmax = f16_lo(max_halves_f16(m4));
+                    float mn;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(mn) : "v"(st_m), "v"(lmax));
+                    const float nm2 = -mn * RNNT_LOG2E;
+                    float e = st_s * __builtin_amdgcn_exp2f(fmaf(st_m, RNNT_LOG2E, nm2));
+                    float e2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        e += __builtin_amdgcn_exp2f(fmaf(f16_lo(q0[k]), RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(f16_hi(q0[k]), RNNT_LOG2E, nm2));
+                        e2 += __builtin_amdgcn_exp2f(fmaf(f16_lo(q1[k]), RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(f16_hi(q1[k]), RNNT_LOG2E, nm2));
+                    }
+                    st_s = e + e2;
+                    st_m = mn;
+                }
+                if (!FR_OFF(4)) {  // the staged group leaves row-major: rows l>>2 and 16 + (l>>2), 16 bytes per lane
+                    u32x4 o0, o1;
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(o0), "=&v"(o1) : "v"(strd) : "memory");
+                    *(u32x4 *)(rowp + lane_off + 64 * g) = o0;
+                    *(u32x4 *)(rowp + (long)V * 32 + lane_off + 64 * g) = o1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(bias_w ^ ((pass & 1) ? 0 : 512)), "v"(bn), "n"(0) : "memory");
+        }
+            FRSTAMP(6 + 3 * pass);
+    }
+    // ---- the over-issued DMAs (chunks NC .. NC+2) must land before this workgroup's LDS is released; all stores done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(g0, true);
+    FRSTAMP(60);
+
+    // ---- log-softmax denominator of cell j: the two column halves (lanes j and j+32), then the two log-probs
+    float den;
+    {
+        const float m_o = __shfl_xor(st_m, 32, 64), s_o = __shfl_xor(st_s, 32, 64);
+        const float M = fmaxf(st_m, m_o);
+        const float S = st_s * __builtin_amdgcn_exp2f((st_m - M) * RNNT_LOG2E) + s_o * __builtin_amdgcn_exp2f((m_o - M) * RNNT_LOG2E);
+        den = M + __logf(S);
+    }
+    const long cell = row0 + j;
+    if (cell < cells) {
+        const int u = (int)(cell % U1);
+        const long bt = cell / U1;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int Ub = len_u(a.target_lens, b, a.U1);
+        if (t < len_t(a.logit_lens, b, a.T) && u <= Ub) {
+            const unsigned short *lrow = a.logits + cell * V;
+            const long si = skew_index(b, t, u, a.D, U1);
+            auto stored = [&](int v) {  // fp16 logit v of this row, stored by THIS wave, read through L2
+                const unsigned w = __hip_atomic_load((const unsigned *)(lrow + (v & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return (v & 1) ? f16_hi(w) : f16_lo(w);
+            };
+            if (half == 0) {
+                const float lb = stored(a.blank);
+                a.denom_s[si] = den;
+                a.lpb_s[si] = lb - den;
+            } else {
+                float le = 0.f;
+                if (u < Ub) {
+                    const int y = a.targets[(long)b * (U1 - 1) + u];
+                    le = stored(y) - den;
+                }
+                a.lpe_s[si] = le;
+            }
+        }
+    }
+}
+
+// H values the register-resident forward is instantiated for (else: the generic kernel above)
+static int bf16_fwd_ra_kc(int H) { return (H == 128 || H == 256 || H == 512 || H == 1024) ? H / 64 : 0; }
+
+template <int KC>
+static void launch_fwd_ra(const Bf16Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = FR_OFF(64) ? 100 * 1024 : 4 * FR_SLOT + 2 * 512 + 4 * 2048;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_joint_fwd_bf16_ra<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_joint_fwd_bf16_ra<KC>, dim3((unsigned)(a.rows_alloc / 128)), dim3(256), lds, st, a);
+}
+
+static void launch_pack_w_fwd_bf16(const Bf16Args &a, hipStream_t st)
+{
+    if (bf16_fwd_ra_kc(a.H)) {
+        const long nf = (long)a.V * a.H / 8;
+        hipLaunchKernelGGL(k_pack_w_fwd_bf16_ra, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W, (u32x4 *)a.wpack_fwd, a.H, nf);
+    } else {
+        const long nf = (long)(bf16_wpack_fwd_bytes(a.H, a.V) / 16);
+        hipLaunchKernelGGL(k_pack_w_fwd_bf16, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W, (u32x4 *)a.wpack_fwd, a.H, a.V,
+                           a.H / 32, nf);
+    }
+}
+
 void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_joint_fwd_bf16, dim3((unsigned)(a.rows_alloc / 128)), dim3(256), 0, st, a);
+    switch (bf16_fwd_ra_kc(a.H)) {
+    case 2: launch_fwd_ra<2>(a, st); break;
+    case 4: launch_fwd_ra<4>(a, st); break;
+    case 8: launch_fwd_ra<8>(a, st); break;
+    case 16: launch_fwd_ra<16>(a, st); break;
+    default: hipLaunchKernelGGL(k_joint_fwd_bf16, dim3((unsigned)(a.rows_alloc / 128)), dim3(256), 0, st, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -700,9 +1132,6 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
 // ---------------------------------------------------------------------------------------
 #define BW_ROWS 32   // cells per stage (2 MFMA k-steps)
 #define BW_NST 4     // ring stages
-typedef short i16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) i16x4 *lds_i16x4_ptr;
-typedef __attribute__((address_space(3))) void *lds_vptr;
 
 __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 {

@@ -363,6 +363,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags;
         h.dw_tab = (long *)(ws + L.counters + 1024);
         g.pred_split_col = H;  // reductions: every dPred slab is 8 t-rows high, as in k_dhidden_gen
+        h.debug = g_debug;
         if (stages & ST_PROD) launch_bf16_producers(h, st);
         if (stages & ST_FWD) launch_joint_fwd_bf16(h, st);  // softmax statistics in its epilogue
         if (stages & ST_LATTICE)
