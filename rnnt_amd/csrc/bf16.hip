@@ -1267,6 +1267,20 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             }
         };
 
+        // Soft lockstep of the tiles of a split.  They walk the same stages and share every operand byte through their
+        // XCD's L2 (G between the h blocks, hidden between the v blocks); nothing else holds them together, and at this
+        // kernel's pace a tile that falls ~10 stages behind finds its lines evicted, becomes its own HBM stream and
+        // slows everybody further — counted: 1.85x the algorithmic traffic.  Every 4th stage a tile publishes its stage
+        // count and looks at its right-hand neighbour's in the ring of the split's tiles (one coherent scalar load,
+        // issued a stage before its value is used); a tile more than DW_LAG stages ahead of that neighbour naps.
+        // Bounded: after DW_NAPS naps without the neighbour moving (a partner that is not resident) the tile stops
+        // looking, so every wave reaches the end whatever the others do.
+        constexpr int DW_LAG = 3, DW_NAPS = 256;
+        int *prog = a.dw_prog ? a.dw_prog + split * 16 : nullptr;
+        bool sync_on = prog != nullptr && tiles > 1 && tiles <= 16;
+        const int *nb = prog ? prog + (tile + 1 < tiles ? tile + 1 : 0) : nullptr;  // the neighbour's word
+        int nb_at = 0x7fffffff;  // the neighbour's stage count as of the last look
+        int done = 0;  // stages behind this workgroup, over all ranges
         int ub = 0;
         while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;  // utterance holding live stage g_lo
         for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
@@ -1289,11 +1303,25 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         landed(X, true);
         for (long st = 0; st < nstage; ++st) {
             const int slot = (int)(st & 3);
+            const int mine = done + (int)st;
+            const bool look = sync_on && (mine & 3) == 0;  // wave-uniform
+            if (look) {
+                // the value requested at the previous look has long landed (lgkmcnt(0) of the barriers since)
+                int naps = 0;
+                while (nb_at + DW_LAG + 4 < mine) {  // (+4: the value is one look old)
+                    if (++naps > DW_NAPS) { sync_on = false; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(nb_at) : "s"(nb) : "memory");
+                }
+                if (tid == 0) __hip_atomic_store(prog + tile, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(nb_at) : "s"(nb) : "memory");  // used at the next look
+            }
             reads(Y, slot, 1);
             mma_step(X, st + 3, (slot + 3) & 3, 0);
             // stage st+1: younger in flight = stage st+2 (8 DMAs) + the 4 pieces just issued
+            // (+ wave 0's progress store now and then: one more outstanding operation only makes the wait stricter)
             asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            lds_barrier();  // B_{st+1}; its lgkmcnt(0) also covers Y
+            lds_barrier();  // B_{st+1}; its lgkmcnt(0) also covers Y and the neighbour's progress word
             landed(Y, false);
             reads(X, (slot + 1) & 3, 0);  // past the last stage: reads a landed, unused slot
             mma_step(Y, st + 3, (slot + 3) & 3, 4);
@@ -1301,7 +1329,9 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the
         lds_barrier();                                     // ring is refilled / the kernel exits
+        done += (int)nstage;
         }
+        if (prog && tid == 0) __hip_atomic_store(prog + tile, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // done: nobody waits for this tile
     }
 
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r
@@ -1344,5 +1374,6 @@ void launch_dw_bf16(const Bf16Args &a, hipStream_t st)
         (void)hipFuncSetAttribute((const void *)k_dw_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, BW_NST * 32768);
         if (dev >= 0) attr_set[dev] = true;
     }
+    if (a.dw_prog) launch_fill32(a.dw_prog, 0u, (size_t)a.n_split * 64, st);
     hipLaunchKernelGGL(k_dw_bf16, dim3(tiles * a.n_split), dim3(256), BW_NST * 32768, st, a);
 }

@@ -125,6 +125,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     {   // + the dW live-row table (bf16 routes) / live-granule list (fp32 route), whichever is larger
         const size_t tab = (2 * (size_t)B + 2) * 8, lst = (bf || x3) ? 0 : dw_list_bytes(B, T, U1, 16);
         L->counters = o; o += 1024 + align_up(tab > lst ? tab : lst);
+        if (bf) o += align_up((size_t)L->n_split * 64);  // k_dw_bf16's progress words, behind the table
     }
     L->total = o;
     if (x3) {  // fp32 hidden + fp32 W pack of the stages that can run on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*):
@@ -362,6 +363,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.B = B; h.T = T; h.U1 = U1; h.H = H; h.V = V; h.blank = blank;
         h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags;
         h.dw_tab = (long *)(ws + L.counters + 1024);
+        h.dw_prog = (int *)(ws + L.counters + 1024 + align_up((2 * (size_t)B + 2) * 8));
         g.pred_split_col = H;  // reductions: every dPred slab is 8 t-rows high, as in k_dhidden_gen
         h.debug = g_debug;
         if (stages & ST_PROD) launch_bf16_producers(h, st);

@@ -113,6 +113,7 @@ struct Bf16Args {
     int flags;  // experiment switches (bits 8..: 256 no stores, 512 no statistics, 1024 no MFMA)
     long *dw_tab;  // 2B+2 longs: live-row table of k_dw_bf16 (k_dw_table, 32-cell granules)
     unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
+    int *dw_prog;  // [n_split][16] progress words of k_dw_bf16's tiles (zeroed by its launcher), or NULL
 };
 size_t bf16_wpack_fwd_bytes(int H, int V);
 size_t bf16_wpack_dh_bytes(int H, int V);
