@@ -691,6 +691,25 @@ def test_bf16_fused_vs_rounding_point_oracle(amd, shape):
         assert_close_grad(k + " vs unrounded", r[k], exact[k], rtol=BF16_GRAD_RTOL_EXACT)
 
 
+@pytest.mark.parametrize("shape,ll,tl", [((2, 70, 0, 256, 128), None, None),            # U1 = 1: every cell its own time step
+                                         ((3, 50, 2, 512, 256), [50, 7, 33], [2, 0, 1]),  # U1 = 3: 10 time steps per wave
+                                         ((2, 200, 30, 128, 128), [200, 20], [30, 5]),    # whole tiles past T_b (hidden only)
+                                         ((1, 37, 6, 1024, 384), None, None),             # H = 1024: one workgroup per CU
+                                         ((5, 3, 40, 256, 128), [3, 1, 2, 3, 1], [40, 0, 13, 40, 7])])  # 123 cells each
+def test_bf16_forward_register_resident_edges(amd, shape, ll, tl):
+    """k_joint_fwd_bf16_ra (H = 128/256/512/1024): a wave's 32 cells spanning many time steps (small U1), tiles that
+    straddle utterances or lie past an utterance's length, the last tile past the lattice."""
+    B, T, U, H, V = shape
+    d = make_inputs(B, T, U, H, V, seed=sum(shape) + 7)
+    if ll is not None:
+        d["logit_lens"] = np.array(ll, dtype=np.int32); d["target_lens"] = np.array(tl, dtype=np.int32)
+    r = _run_fused(amd, d, dtype="bf16")
+    ref = oracle_fused_bf16(d)
+    assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r[k], ref[k], rtol=BF16_GRAD_RTOL)
+
+
 def test_bf16_rejects_unsupported_dims(amd):
     d = make_inputs(2, 5, 2, 64, 128, seed=3)
     with pytest.raises(RuntimeError, match="RNNT_DTYPE_BF16"):
