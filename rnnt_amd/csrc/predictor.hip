@@ -298,37 +298,33 @@ int rnnt_engine_conv_predictor_bwd(const int64_t *ids, int B, int U1, int S, int
     // output LayerNorm: dz, d gamma = colsum(dy * zhat), d beta = colsum(dy)
     hipLaunchKernelGGL(k_ln_bwd<false>, dim3((M + 3) / 4), dim3(256), 0, st, ws + L.z, nullptr, 0, p->ln_out_w,
                        ws + L.st2, grad_out, M, O, ws + L.dz, ws + L.t);
-    launch_colsum(ws + L.t, O, M, O, gp[9], cs, st);
-    launch_colsum(grad_out, O, M, O, gp[10], cs, st);
+    launch_colsum_pair(ws + L.t, grad_out, O, M, O, gp[9], gp[10], cs, st);
     // linear: dW = dz^T g2, db = colsum(dz), dg2 = dz W
-    const int KS = sgemm_tn_splits(M);
-    auto wgrad = [&](SgArgs a, float *out) {  // contraction split over KS workgroups, slabs summed in order
+    // weight gradient: contraction split over KS workgroups; the slabs, the conv weights' layout and the bias gradient's
+    // second stage are finished by one launch (everything in fixed order)
+    auto wgrad = [&](SgArgs a, const float *dy, int out_c, int in_c, float *dW, float *db) {
+        const int KS = sgemm_tn_splits_for(M, a.N, a.K, a.taps);
         a.ksplit = KS; a.C = ws + L.slabs;
         launch_sgemm_tn(a, st);
-        launch_sum_slabs(ws + L.slabs, out, (long)a.taps * a.N * a.K, KS, st);
+        launch_colsum_stage1(dy, out_c, M, out_c, cs, st);
+        launch_wgrad_finish(ws + L.slabs, KS, dW, out_c, in_c, a.taps, cs, colsum_slabs(M), out_c, db, st);
     };
-    wgrad(sg(ws + L.dz, O, ws + L.g2, E, nullptr, E, M, O, E, 1, M), gp[7]);
-    launch_colsum(ws + L.dz, O, M, O, gp[8], cs, st);
+    wgrad(sg(ws + L.dz, O, ws + L.g2, E, nullptr, E, M, O, E, 1, M), ws + L.dz, O, E, gp[7], gp[8]);
     launch_sgemm_nn(sg(ws + L.dz, O, p->linear_w, E, ws + L.dg, E, M, E, O, 1, M), st);
-    // conv2: through dropout + gelu, then dWp2 / db2 / dg1
+    // conv2: through dropout + gelu, then dW2 / db2 / dg1
     hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)(((long)M * E + 255) / 256)), dim3(256), 0, st, ws + L.dg,
                        ws + L.y2, keep2, scale, (long)M * E, ws + L.dyp);
-    wgrad(sg(ws + L.dyp, E, ws + L.g1, E, nullptr, E, M, E, E, 5, U1), ws + L.dwp);
-    launch_unpack_conv_w(ws + L.dwp, gp[5], E, E, 5, st);
-    launch_colsum(ws + L.dyp, E, M, E, gp[6], cs, st);
+    wgrad(sg(ws + L.dyp, E, ws + L.g1, E, nullptr, E, M, E, E, 5, U1), ws + L.dyp, E, E, gp[5], gp[6]);
     launch_sgemm_nn(sg(ws + L.dyp, E, ws + L.wp2, E, ws + L.dg, E, M, E, E, 5, U1), st);
     // conv1
     hipLaunchKernelGGL(k_gelu_bwd, dim3((unsigned)(((long)M * E + 255) / 256)), dim3(256), 0, st, ws + L.dg,
                        ws + L.y1, keep1, scale, (long)M * E, ws + L.dyp);
-    wgrad(sg(ws + L.dyp, E, ws + L.x1, E, nullptr, E, M, E, E, 3, U1), ws + L.dwp);
-    launch_unpack_conv_w(ws + L.dwp, gp[3], E, E, 3, st);
-    launch_colsum(ws + L.dyp, E, M, E, gp[4], cs, st);
+    wgrad(sg(ws + L.dyp, E, ws + L.x1, E, nullptr, E, M, E, E, 3, U1), ws + L.dyp, E, E, gp[3], gp[4]);
     launch_sgemm_nn(sg(ws + L.dyp, E, ws + L.wp1, E, ws + L.dg, E, M, E, E, 3, U1), st);
     // input LayerNorm (its input is the embedding row) and the embedding table
     hipLaunchKernelGGL(k_ln_bwd<true>, dim3((M + 3) / 4), dim3(256), 0, st, p->embedding, ids, S, p->ln_in_w,
                        ws + L.st1, ws + L.dg, M, E, ws + L.dz, ws + L.t);
-    launch_colsum(ws + L.t, E, M, E, gp[1], cs, st);
-    launch_colsum(ws + L.dg, E, M, E, gp[2], cs, st);
+    launch_colsum_pair(ws + L.t, ws + L.dg, E, M, E, gp[1], gp[2], cs, st);
     hipLaunchKernelGGL(k_embed_bwd, dim3(S), dim3(256), 0, st, ids, ws + L.dz, M, E, S, gp[0]);
     return status("rnnt_engine_conv_predictor_bwd");
 }
@@ -373,11 +369,11 @@ int rnnt_engine_linear_bwd(const float *x, int64_t ldx, const float *W, const fl
     {
         float *slabs = (float *)workspace + ((colsum_scratch_floats(M, N) + 63) & ~(size_t)63);
         SgArgs a = sg(dy, N, x, ldx, slabs, K, M, N, K, 1, M);
-        a.ksplit = sgemm_tn_splits(M);
+        a.ksplit = sgemm_tn_splits_for(M, N, K, 1);
         launch_sgemm_tn(a, st);
-        launch_sum_slabs(slabs, dW, (long)N * K, a.ksplit, st);
+        if (db) launch_colsum_stage1(dy, N, M, N, (float *)workspace, st);
+        launch_wgrad_finish(slabs, a.ksplit, dW, N, K, 1, (const float *)workspace, colsum_slabs(M), N, db, st);
     }
-    if (db) launch_colsum(dy, N, M, N, db, (float *)workspace, st);
     if (dx) launch_sgemm_nn(sg(dy, N, W, K, dx, K, M, K, N, 1, M), st);
     return status("rnnt_engine_linear_bwd");
 }

@@ -70,13 +70,15 @@ __global__ __launch_bounds__(256) void k_sgemm_nt(SgArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.x[s], o.w[q][s], acc[q], 0, 0, 0);
     };
-    if (wave < total) {
-        Ops cur, nxt;
+    if (wave < total) {  // operands requested two chunks ahead (one chunk of 16 MFMAs does not cover an L2 round trip)
+        Ops cur, nxt, nx2;
         load(cur, wave);
+        if (wave + 4 < total) load(nxt, wave + 4);
         for (int c = wave; c < total; c += 4) {
-            if (c + 4 < total) load(nxt, c + 4);
+            if (c + 8 < total) load(nx2, c + 8);
             compute(cur);
             cur = nxt;
+            nxt = nx2;
         }
     }
     reduce_to_wave0<4>(acc, red, wave, lane);
@@ -138,13 +140,15 @@ __global__ __launch_bounds__(256) void k_sgemm_nn(SgArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y[s], o.w[s][q], acc[q], 0, 0, 0);
     };
-    if (wave < total) {
-        Ops cur, nxt;
+    if (wave < total) {  // operands requested two chunks ahead (one chunk of 16 MFMAs does not cover an L2 round trip)
+        Ops cur, nxt, nx2;
         load(cur, wave);
+        if (wave + 4 < total) load(nxt, wave + 4);
         for (int c = wave; c < total; c += 4) {
-            if (c + 4 < total) load(nxt, c + 4);
+            if (c + 8 < total) load(nx2, c + 8);
             compute(cur);
             cur = nxt;
+            nxt = nx2;
         }
     }
     reduce_to_wave0<4>(acc, red, wave, lane);
@@ -239,25 +243,46 @@ __global__ __launch_bounds__(256) void k_pack_conv_w(const float *__restrict__ w
     else wp[pidx] = w[idx];
 }
 
-// stage 1: slab s sums rows [64s, 64s+64) of 256 columns; stage 2 sums the slabs
-__global__ __launch_bounds__(256) void k_colsum1(const float *__restrict__ Y, long ldy, int M, int N,
-                                                 float *__restrict__ scratch)
+// Column sums in two launches, fixed order (bitwise reproducible).  Stage 1: a workgroup sums 256 rows of 64 columns —
+// thread (cq = tid & 15, rl = tid >> 4) adds rows rl, rl+16, .. of column quad cq (16-byte loads, a row of the
+// workgroup = 256 contiguous bytes), the 16 row lanes are combined through LDS in index order; stage 2 sums the
+// ceil(M/256) slabs.  (Round 2's form — one thread per column, 64-row slabs — spent 16 + 12 us on 13 MB: the second
+// stage walked 50-100 slabs serially; seven of these pairs are a fifth of the predictor's backward.)
+__global__ __launch_bounds__(256) void k_colsum1(const float *__restrict__ Y0, const float *__restrict__ Y1, long ldy, int M, int N,
+                                                 float *__restrict__ scratch0)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int m0 = blockIdx.y * 64, m1 = min(m0 + 64, M);
-    float s = 0.f;
-    for (int m = m0; m < m1; ++m) s += Y[(long)m * ldy + n];
-    scratch[(long)blockIdx.y * N + n] = s;
+    __shared__ f32x4 red[256];
+    const float *Y = blockIdx.z ? Y1 : Y0;  // two tensors of one shape in one launch
+    float *scratch = scratch0 + (long)blockIdx.z * gridDim.y * N;
+    const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
+    const int n = blockIdx.x * 64 + 4 * cq;
+    const int m0 = blockIdx.y * 256;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int m = m0 + rl + 16 * j;
+            if (m < M) s += *(const f32x4 *)(Y + (long)m * ldy + n);
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[16 * k + cq];
+        *(f32x4 *)(scratch + (long)blockIdx.y * N + n) = s;
+    }
 }
-__global__ __launch_bounds__(256) void k_colsum2(const float *__restrict__ scratch, int nslab, int N,
-                                                 float *__restrict__ out)
+__global__ __launch_bounds__(256) void k_colsum2(const float *__restrict__ scratch0, int nslab, int N,
+                                                 float *__restrict__ out0, float *__restrict__ out1)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    const float *scratch = scratch0 + (long)blockIdx.y * nslab * N;
+    float *out = blockIdx.y ? out1 : out0;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (n >= N) return;
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += scratch[(long)k * N + n];
-    out[n] = s;
+    f32x4 s = *(const f32x4 *)(scratch + n);
+    for (int k = 1; k < nslab; ++k) s += *(const f32x4 *)(scratch + (long)k * N + n);
+    *(f32x4 *)(out + n) = s;
 }
 
 __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, float *__restrict__ out,
@@ -270,7 +295,44 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
     ((f32x4 *)out)[idx] = s;
 }
 
+// The tail of a weight-gradient GEMM in ONE launch: dW = sum of the split-K slabs (conv: written back in torch's
+// [out][in][tap] order from the packed [tap][out][in] the GEMM produced) and, in the blocks behind those, the second
+// stage of the bias gradient's column sum.  Fixed order throughout.
+__global__ __launch_bounds__(256) void k_wgrad_finish(const float *__restrict__ slabs, int ns, float *__restrict__ dW, int out_c,
+                                                      int in_c, int taps, int nbw, const float *__restrict__ cs, int nslab, int N,
+                                                      float *__restrict__ db)
+{
+    if ((int)blockIdx.x >= nbw) {  // bias part
+        const int n = (((int)blockIdx.x - nbw) * 256 + threadIdx.x) * 4;
+        if (n >= N) return;
+        f32x4 s = *(const f32x4 *)(cs + n);
+        for (int k = 1; k < nslab; ++k) s += *(const f32x4 *)(cs + (long)k * N + n);
+        *(f32x4 *)(db + n) = s;
+        return;
+    }
+    const long n4 = (long)taps * out_c * in_c / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // one packed quad: (tap, co, ci .. ci+3)
+    if (idx >= n4) return;
+    f32x4 s = ((const f32x4 *)slabs)[idx];
+    for (int k = 1; k < ns; ++k) s += ((const f32x4 *)slabs)[(long)k * n4 + idx];
+    if (taps == 1) { ((f32x4 *)dW)[idx] = s; return; }
+    const long e = idx * 4;
+    const int ci = (int)(e % in_c);
+    const long tc = e / in_c;
+    const int co = (int)(tc % out_c), t = (int)(tc / out_c);
+    float *o = dW + ((long)co * in_c + ci) * taps + t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[(long)q * taps] = s[q];
+}
+
 }  // namespace
+
+void launch_wgrad_finish(const float *slabs, int ns, float *dW, int out_c, int in_c, int taps, const float *cs, int nslab, int N,
+                         float *db, hipStream_t st)
+{
+    const int nbw = (int)(((long)taps * out_c * in_c / 4 + 255) / 256), nbb = db ? (N / 4 + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_wgrad_finish, dim3(nbw + nbb), dim3(256), 0, st, slabs, ns, dW, out_c, in_c, taps, nbw, cs, nslab, N, db);
+}
 
 void launch_sgemm_nt(const SgArgs &a, hipStream_t st)
 {
@@ -287,6 +349,18 @@ void launch_sgemm_tn(const SgArgs &a, hipStream_t st)
 }
 // one range per ~256 contraction rows, at most 16: a few hundred MFMA k-steps per wave
 int sgemm_tn_splits(int Mc) { const int s = (Mc + 255) / 256; return s < 1 ? 1 : (s > 16 ? 16 : s); }
+// Splits for ONE weight-gradient GEMM, never more than sgemm_tn_splits(Mc) (which sizes the slab buffer).  Each split
+// ends in a 3-round LDS reduction of its 256 x 128 tile and writes a full [taps][N][K] slab, so a split should carry
+// ~450 contraction rows — but the grid should also fill the chip once.  Measured on the predictor's three GEMMs
+// (tools/bench_predictor.py, fwd+bwd): 3 232 rows 1.171 ms with 13 splits each, 1.152 with 6 / 10 / 13; 6 432 rows
+// 1.923 with 16 each, 1.999 with 6 / 10 / 16, 2.062 with 4 / 6 / 8.
+int sgemm_tn_splits_for(int Mc, int N, int K, int taps)
+{
+    const int per = ((N + 127) / 128) * ((K + 127) / 128) * taps;
+    const int by_rows = (Mc + 447) / 448, by_fill = (256 + per - 1) / per;
+    const int s = by_rows > by_fill ? by_rows : by_fill, cap = sgemm_tn_splits(Mc);
+    return s < 1 ? 1 : (s > cap ? cap : s);
+}
 void launch_sum_slabs(const float *slabs, float *out, long n, int ns, hipStream_t st)
 {
     hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slabs, out, n / 4, ns);
@@ -301,10 +375,21 @@ void launch_unpack_conv_w(const float *wp, float *w, int out_c, int in_c, int ta
     const long n = (long)out_c * in_c * taps;
     hipLaunchKernelGGL(k_pack_conv_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, const_cast<float *>(wp), out_c, in_c, taps, 1);
 }
-size_t colsum_scratch_floats(int M, int N) { return (size_t)((M + 63) / 64) * N; }
+size_t colsum_scratch_floats(int M, int N) { const int s = (M + 63) / 64; return (size_t)(s < 2 ? 2 : s) * N; }  // >= two tensors' 256-row slabs
 void launch_colsum(const float *Y, long ldy, int M, int N, float *out, float *scratch, hipStream_t st)
 {
-    const int nslab = (M + 63) / 64;
-    hipLaunchKernelGGL(k_colsum1, dim3((N + 255) / 256, nslab), dim3(256), 0, st, Y, ldy, M, N, scratch);
-    hipLaunchKernelGGL(k_colsum2, dim3((N + 255) / 256), dim3(256), 0, st, scratch, nslab, N, out);
+    const int nslab = colsum_slabs(M);  // (colsum_scratch_floats still sizes the scratch for 64-row slabs: room for 4 tensors)
+    hipLaunchKernelGGL(k_colsum1, dim3((N + 63) / 64, nslab), dim3(256), 0, st, Y, Y, ldy, M, N, scratch);
+    hipLaunchKernelGGL(k_colsum2, dim3((N / 4 + 255) / 256), dim3(256), 0, st, scratch, nslab, N, out, out);
+}
+int colsum_slabs(int M) { return (M + 255) / 256; }
+void launch_colsum_stage1(const float *Y, long ldy, int M, int N, float *scratch, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_colsum1, dim3((N + 63) / 64, colsum_slabs(M)), dim3(256), 0, st, Y, Y, ldy, M, N, scratch);
+}
+void launch_colsum_pair(const float *Y0, const float *Y1, long ldy, int M, int N, float *out0, float *out1, float *scratch, hipStream_t st)
+{
+    const int nslab = colsum_slabs(M);
+    hipLaunchKernelGGL(k_colsum1, dim3((N + 63) / 64, nslab, 2), dim3(256), 0, st, Y0, Y1, ldy, M, N, scratch);
+    hipLaunchKernelGGL(k_colsum2, dim3((N / 4 + 255) / 256, 2), dim3(256), 0, st, scratch, nslab, N, out0, out1);
 }

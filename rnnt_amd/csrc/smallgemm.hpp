@@ -35,7 +35,8 @@ struct SgArgs {
 void launch_sgemm_nt(const SgArgs &a, hipStream_t st);
 void launch_sgemm_nn(const SgArgs &a, hipStream_t st);  // conv: shift(tap) = (taps-1) - tap (transposed conv)
 void launch_sgemm_tn(const SgArgs &a, hipStream_t st);
-int sgemm_tn_splits(int Mc);  // how many ranges launch_sgemm_tn callers should ask for
+int sgemm_tn_splits(int Mc);  // upper bound of the ranges a launch_sgemm_tn caller asks for (sizes the slab buffer)
+int sgemm_tn_splits_for(int Mc, int N, int K, int taps);  // the ranges to ask for in one GEMM (<= sgemm_tn_splits(Mc))
 // out[i] = sum_s slabs[s][i], i < n (n % 4 == 0), fixed order
 void launch_sum_slabs(const float *slabs, float *out, long n, int ns, hipStream_t st);
 // conv weight [out][in][tap] (torch Conv1d) -> [tap][out][in]; and back (gradient)
@@ -44,3 +45,12 @@ void launch_unpack_conv_w(const float *wp, float *w, int out_c, int in_c, int ta
 // out[n] = sum_m Y[m,n] (fixed order)
 void launch_colsum(const float *Y, long ldy, int M, int N, float *out, float *scratch, hipStream_t st);
 size_t colsum_scratch_floats(int M, int N);
+int colsum_slabs(int M);  // slabs stage 1 leaves in `scratch` ([slab][N])
+// two tensors of one shape (both strides ldy) in the same two launches
+void launch_colsum_pair(const float *Y0, const float *Y1, long ldy, int M, int N, float *out0, float *out1, float *scratch, hipStream_t st);
+// stage 1 only: the slabs are summed by launch_wgrad_finish
+void launch_colsum_stage1(const float *Y, long ldy, int M, int N, float *scratch, hipStream_t st);
+// dW = sum of `ns` split-K slabs (taps > 1: packed [tap][out][in] -> torch's [out][in][tap]) and db = sum of the colsum
+// slabs in `cs` (db NULL: none), one launch
+void launch_wgrad_finish(const float *slabs, int ns, float *dW, int out_c, int in_c, int taps, const float *cs, int nslab, int N,
+                         float *db, hipStream_t st);

@@ -1,6 +1,6 @@
 """ConvPredictor forward+backward: the engine's kernels (rnnt_amd.ConvPredictor) vs the same op
 sequence in eager torch (embedding, LayerNorm, pad + Conv1d, gelu, Linear, LayerNorm on rocBLAS /
-MIOpen), at the reference's sizes (S=1024, E=512, O=1024).  python tools/bench_predictor.py"""
+MIOpen), at the reference's sizes (S=1024, E=512, O=1024).  python tools/bench_predictor.py [BxU1 ...]"""
 import os
 import sys
 
@@ -39,7 +39,8 @@ def timeit(f, n=30):
     return e0.elapsed_time(e1) / n
 
 
-for B, U1 in ((2, 51), (8, 51), (8, 101), (32, 101), (32, 201)):
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(2, 51), (8, 51), (8, 101), (32, 101), (32, 201)]
+for B, U1 in SIZES:
     S, E, O = 1024, 512, 1024
     ids = torch.randint(0, S, (B, U1), device="cuda")
     G = torch.randn(B, U1, O, device="cuda")
