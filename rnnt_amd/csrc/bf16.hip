@@ -861,6 +861,12 @@ void launch_joint_fwd_bf16(const Bf16Args &a, hipStream_t st)
 // FIRST = false launch per further 512 columns (`hp`), which finds G in place of the logits, copies
 // it into the exchange instead of producing it, and stores nothing but its slabs.
 // ---------------------------------------------------------------------------------------
+// Diagnostic builds only (-DDH_EXP=bits, tools/build_bf16_variants.sh): parts of k_dhidden_bf16 compiled out — 1 no MFMAs,
+// 2 no G arithmetic (exponentials), 4 no G stores, 8 no logits loads, 16 no W staging (loads + LDS writes), 32 no epilogue
+#ifndef DH_EXP
+#define DH_EXP 0
+#endif
+#define DH_OFF(bit) ((DH_EXP) & (bit))
 #define BG_BT 8
 #define BG_BU 16
 template <bool FIRST>
@@ -919,6 +925,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
 
     auto produce = [&](const u32x4 &x, int c, int slot) {
         if constexpr (!FIRST) { s_g[slot * 512 + gdst] = x; return; }
+        if (DH_OFF(2)) { s_g[slot * 512 + gdst] = x; return; }
         float g[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -954,19 +961,21 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
         gst[i] = (u32x4 *)(a.logits + (gst_ok[i] ? ((long)b * T + pt) * U1 + su : zrow) * V) + sp;
     }
     auto wload = [&](u32x4 (&w)[4], int c) {
+        if (DH_OFF(16)) return;
         const u32x4 *p = wp + (long)(c < VC ? c : VC - 1) * 2048;
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = p[i * 64];
     };
     auto wstore = [&](const u32x4 (&w)[4], int slot) {
+        if (DH_OFF(16)) return;
         u32x4 *p = s_b + slot * 2048 + (wave * 4) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[i * 64] = w[i];
     };
-    auto xload = [&](u32x4 &x, int c) { x = xsrc[4 * (c < VC ? c : VC - 1)]; };
+    auto xload = [&](u32x4 &x, int c) { if (!DH_OFF(8)) x = xsrc[4 * (c < VC ? c : VC - 1)]; };
 
-    u32x4 xr[4];  // logits ring (slot = chunk & 3), 4 chunks ahead of production
-    u32x4 wx[4], wy[4];  // staged W: even / odd chunks
+    u32x4 xr[4] = {};  // logits ring (slot = chunk & 3), 4 chunks ahead of production
+    u32x4 wx[4] = {}, wy[4] = {};  // staged W: even / odd chunks
     xload(xr[0], 0); xload(xr[1], 1); xload(xr[2], 2); xload(xr[3], 3);
     wload(wx, 0);
     wload(wy, 1);
@@ -1001,8 +1010,10 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
                     if (n + DEPTH < 8) bf[(n + DEPTH) % (DEPTH + 1)] = pb[(((n + DEPTH) >> 2) * 16 + ((n + DEPTH) & 3)) * 64];
-                    acc[n & 3] = mfma_bf16(af[0][n >> 2], bf[n % (DEPTH + 1)], acc[n & 3]);
-                    acc[4 + (n & 3)] = mfma_bf16(af[1][n >> 2], bf[n % (DEPTH + 1)], acc[4 + (n & 3)]);
+                    if (!DH_OFF(1)) {
+                        acc[n & 3] = mfma_bf16(af[0][n >> 2], bf[n % (DEPTH + 1)], acc[n & 3]);
+                        acc[4 + (n & 3)] = mfma_bf16(af[1][n >> 2], bf[n % (DEPTH + 1)], acc[4 + (n & 3)]);
+                    }
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 4 + DEPTH + 2, 0);
 #pragma unroll
@@ -1012,7 +1023,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 2 * DEPTH, 0);
             }
-            if (FIRST && !(q & 1) && !RNNT_XP(a.flags, 256)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
+            if (FIRST && !(q & 1) && !RNNT_XP(a.flags, 256) && !DH_OFF(4)) {  // chunk c+1 is odd: the pair (c, c+1) is complete
                 __builtin_amdgcn_sched_barrier(0);
                 const u32x4 gb0 = s_g[gsrc], gb1 = s_g[gsrc + 8];
                 if (gst_ok[0]) gst[0][4 * c] = gb0;
@@ -1024,7 +1035,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
 
     // ---- epilogue.  Accumulator register r of tile 4mt+q (mt = 0,1): row (r&3) + 8(r>>2) + 4*half
     // of M-tile 2wm+mt = (t-row 2(2wm+mt) + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 128wn + 4j + q.
-    if (RNNT_XP(a.flags, 8192)) return;
+    if (RNNT_XP(a.flags, 8192) || DH_OFF(32)) return;
     float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
     const int col0 = 512 * hp + 128 * wn + 4 * j;
