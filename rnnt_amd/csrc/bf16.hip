@@ -1035,7 +1035,11 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
 
     // ---- epilogue.  Accumulator register r of tile 4mt+q (mt = 0,1): row (r&3) + 8(r>>2) + 4*half
     // of M-tile 2wm+mt = (t-row 2(2wm+mt) + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 128wn + 4j + q.
-    if (RNNT_XP(a.flags, 8192) || DH_OFF(32)) return;
+    if (RNNT_XP(a.flags, 8192) || DH_OFF(32)) {  // (the accumulators stay "used": without this the MFMAs are dead code too)
+#pragma unroll
+        for (int tl = 0; tl < 8; ++tl) asm volatile("" :: "a"(acc[tl]));
+        return;
+    }
     float *s_red = (float *)s_mem;  // [8 waves][64 lanes][33]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
     const int col0 = 512 * hp + 128 * wn + 4 * j;

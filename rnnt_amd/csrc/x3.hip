@@ -528,8 +528,17 @@ size_t x3_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
             a.debug[(cs - 8) * 8 + (slot)] = t_;                                                            \
         }                                                                                                   \
     } while (0)
+#define XESTAMP(k)                                                                                          \
+    do {                                                                                                    \
+        if (a.debug && blockIdx.x == 0 && wave == XS_WAVE && lane == 0 && it == 3) {                         \
+            unsigned long long t_;                                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+            a.debug[128 + (k)] = t_;                                                                        \
+        }                                                                                                   \
+    } while (0)
 #else
 #define XSTAMP(slot) do {} while (0)
+#define XESTAMP(k) do {} while (0)
 #endif
 __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int ntiles)
 {
@@ -687,6 +696,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
         // first pass outside the loop over the others (a branch between two k loops, like a conditional accumulator
         // re-initialisation inside one, makes hipcc carry the 256 accumulator registers through VGPR phis and spill)
         auto run_pass = [&](auto store_c, const int pass) {
+          XESTAMP(32 * pass + 0);
           acc_init(pass);
           // one k-step; STORE: first pass — the produced planes also go to memory.  Two straight-line instantiations
           // (hipcc counts vmcnt exactly only through straight-line code).
@@ -759,6 +769,13 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
           // pass complete: store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column groups exist
           // or not for the whole wave.  The row loop is ONE basic block per case; the store address is a scalar row
           // pointer + one 32-bit per-lane offset.
+          XESTAMP(32 * pass + 1);
+          if (X3_OFF(16)) {  // (the accumulators stay "used": without this the MFMAs are dead code too)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("" :: "a"(acc[mt][q]));
+          }
           if (!X3_OFF(16)) {
             const int cw = 512 * pass + 256 * wn;
             const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
@@ -806,17 +823,21 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
+                        if ((r & 7) == 7) XESTAMP(32 * pass + 2 + 2 * mt + (r >> 3));
                     }
             };
             if (cw + 128 < V) epilogue(X3Int<1>{});
             else if (cw < V) epilogue(X3Int<0>{});
           }
+          XESTAMP(32 * pass + 6);
         };
         run_pass(X3Int<1>{}, 0);
         for (int pass = 1; pass < npass; ++pass) run_pass(X3Int<0>{}, pass);
 
+        XESTAMP(96);
         // ---- log-softmax denominators: the two column halves (wn) of every row
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XESTAMP(97);
         __syncthreads();  // every logits / hidden store of the workgroup has left its wave; s_part complete
         if (tid < 128) {
             const float m0 = s_part[tid * 2], s0 = s_part[tid * 2 + 1];
@@ -855,6 +876,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
                 }
             }
         }
+        XESTAMP(98);
         tile = next;
     }
 }
@@ -1186,7 +1208,13 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     // ---- epilogue.  Accumulator register rr = 8rh + r7 of M tile (2wm + mt), column tile q: row (rr&3) + 8(rr>>2) +
     // 4half of its 32 = t row 2(2wm+mt) + rh, u slot 8(r7>>2) + (r7&3) + 4half; column 512hp + 256wn + 128(q>>2) +
     // 4i + (q&3).  hidden = hi + mid + lo of the planes (exact), through a raw buffer over the tile's rows.
-    if (X3_OFF(16)) return;
+    if (X3_OFF(16)) {  // (the accumulators stay "used": without this the MFMAs are dead code too)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" :: "a"(acc[mt][q]));
+        return;
+    }
     float (*s_red)[64][65] = (float (*)[64][65])s_dh;  // [wn][lane][8 u slots x 8 columns]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
     const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
