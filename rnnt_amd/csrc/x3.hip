@@ -561,10 +561,18 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
     const int xa = lds0 + 2 * XF_WSLOT + (2 * wm) * 3072 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
     const int xw = lds0 + 2 * XF_WSLOT + wave * 3072 + 16 * lane;       // A write: M tile `wave` (this lane's own fragment slot)
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                 // W read: tiles 8wn .. 8wn+7 of each plane
-    const u32x4 *wsrc = (const u32x4 *)a.wpack_fwd + (wave * 12) * 64 + lane;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, npass * KC * 49152, 0x00020000);
+    const int wvo = lane * 16;
 
     // Persistent workgroups (one per CU: 120 KiB of LDS), tiles from one atomic counter, the next tile requested a
     // tile ahead.
+#ifdef RNNT_STAMPS
+    if (a.debug && blockIdx.x == 0 && tid == 0) {  // clock of this launch: core-clock ticks per 100 MHz reference tick
+        unsigned long long t0_, r0_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_), "=s"(r0_)::"memory");
+        a.debug[128 + 100] = t0_; a.debug[128 + 101] = r0_;
+    }
+#endif
     if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
     __syncthreads();
     int tile = s_next[0];
@@ -647,10 +655,10 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
             if (!X3_OFF(128)) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; hdst[2 * kcs + 2 * ps] = P.pl; }
         };
         // piece n (0..11) of this wave's share of W k-step cs -> ring slot cs & 1
-        auto wdma = [&](int cs, int n) {
+        auto wdma = [&](int cs, int n) {  // raw-buffer form: scalar base and offsets, one constant per-lane offset register
             if (X3_OFF(8)) return;
-            __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cs * 3072 + n * 64),
-                                             (lds_vptr)(s_fw + (cs & 1) * XF_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fw + (cs & 1) * XF_WSLOT + (wave * 12 + n) * 1024), 16, wvo,
+                                                     (cs * 48 + wave * 12 + n) * 1024, 0, 0);
         };
 
         if (dead) {  // hidden rows only (finite values for k_dw_x3), no products
@@ -879,6 +887,13 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
         XESTAMP(98);
         tile = next;
     }
+#ifdef RNNT_STAMPS
+    if (a.debug && blockIdx.x == 0 && tid == 0) {
+        unsigned long long t1_, r1_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_), "=s"(r1_)::"memory");
+        a.debug[128 + 102] = t1_; a.debug[128 + 103] = r1_;
+    }
+#endif
 }
 
 bool x3_fwd_ok(int U1, int H, int V) { return H % 128 == 0 && V % 128 == 0 && (long)128 * H * 2 < 0x7fffffffL; }
@@ -1034,7 +1049,9 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     const int xa = lds0 + 2 * XG_WSLOT + (2 * wm) * 3072 + 16 * lane;   // exchange read: M tiles 2wm, 2wm+1
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                  // W read: tiles 8wn .. 8wn+7 of each plane
     // W DMA: wave w copies pieces 12w .. 12w+11 of the k-step's 48 (piece = 1 KiB = one (plane, tile))
-    const u32x4 *wsrc = (const u32x4 *)a.wpack_dh + (long)hp * VC * 3072 + (wave * 12) * 64 + lane;
+    // W k-steps by raw-buffer LDS-DMA: scalar base (this launch's 512-column pass) and offsets, one constant per-lane offset
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((char *)a.wpack_dh + (long)hp * VC * 49152, 0, VC * 49152, 0x00020000);
+    const int wvo = lane * 16;
 
     struct Raw { f32x4 x0, x1; u32x4 l; };  // FIRST: 8 fp32 logits; else: hi | mid (as x0, x1 bits) and lo planes
     auto xload = [&](Raw &r, int c, int part = 3) {  // part: 1 first half, 2 second half, 3 both (FIRST)
@@ -1109,8 +1126,8 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     auto wdma = [&](int c, int n) {  // piece n (0..11) of this wave's share of W k-step c -> ring slot c & 1
         const int cc = c < VC ? c : VC - 1;
         if (X3_OFF(8)) return;
-        __builtin_amdgcn_global_load_lds((const void *)(wsrc + (long)cc * 3072 + n * 64),
-                                         (lds_vptr)(s_dh + (c & 1) * XG_WSLOT + (wave * 12 + n) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + (c & 1) * XG_WSLOT + (wave * 12 + n) * 1024), 16, wvo,
+                                                 (cc * 48 + wave * 12 + n) * 1024, 0, 0);
     };
 
     Raw xr[4];  // raw ring (slot = k-step & 3), 4 k-steps ahead of production

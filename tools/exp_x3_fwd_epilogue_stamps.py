@@ -21,3 +21,5 @@ for p in range(V // 512):
     b = 32 * p
     print(f"pass {p}: k loop {x[b+1]-x[b]}, epilogue quarters {x[b+2]-x[b+1]} {x[b+3]-x[b+2]} {x[b+4]-x[b+3]} {x[b+5]-x[b+4]}, total epilogue {x[b+6]-x[b+1]}")
 print(f"store drain {x[97]-x[96]}, finalisation {x[98]-x[97]}, tile {x[98]-x[0]}")
+dt, dr = x[102] - x[100], x[103] - x[101]
+print(f"workgroup 0 lifetime: {dt} s_memtime ticks, {dr} s_memrealtime ticks (100 MHz): {dr / 100e6 * 1e3:.2f} ms, s_memtime rate {dt / dr * 100:.0f} MHz")
