@@ -1199,12 +1199,18 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             soff[i] = (int)((4 * i + (lane >> 4)) * rstride) + 16 * ((lane & 15) ^ (((lane >> 4) << 2) | (i & 3)));
+        // (raw-buffer form: the 32 rows of a stage as a buffer with a wave-uniform base — scalar arithmetic only; the
+        // per-lane part of an address is the 32-bit soff.  A global_load_lds with a 64-bit per-lane address costs the
+        // issuing wave more: measured on the bf16x3 forward)
+        auto stage_rsrc = [&](long st) {
+            return __builtin_amdgcn_make_buffer_rsrc((void *)(src + st * (BW_ROWS * rstride)), 0, (int)(BW_ROWS * rstride), 0x00020000);
+        };
         auto dma_stage = [&](long st, int slot) {
-            const char *p = src + st * (BW_ROWS * rstride);
+            const __amdgpu_buffer_rsrc_t r = stage_rsrc(st);
             char *dst = s_ring + slot * 32768 + wave * 8192;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_global_load_lds((const void *)(p + soff[i]), (lds_vptr)(dst + 1024 * i), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(dst + 1024 * i), 16, soff[i], 0, 0, 0);
         };
         // ---- transposed fragment reads.  Fragment of 32-column tile m, k-step ks: lane
         // (g = lane>>4, q = (lane&15)>>2, p = lane&3) reads rows 16ks + 8(g>>1) + 4sec + q at
@@ -1226,8 +1232,8 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         const int lds0 = (int)(size_t)(lds_vptr)s_ring;  // LDS byte address of the ring
         const int a_tile = lds0 + wm * 8192, b_tile = lds0 + 16384 + wn * 8192;
         auto dma_piece = [&](long st, int slot, int i) {
-            __builtin_amdgcn_global_load_lds((const void *)(src + st * (BW_ROWS * rstride) + soff[i]),
-                                             (lds_vptr)(s_ring + slot * 32768 + wave * 8192 + 1024 * i), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(stage_rsrc(st), (lds_vptr)(s_ring + slot * 32768 + wave * 8192 + 1024 * i), 16,
+                                                     soff[i], 0, 0, 0);
         };
         struct Frags { u32x2 al[4], ah[4], bl[4], bh[4]; };
         auto reads = [&](Frags &f, int slot, int ks) {  // 16 transposed reads, NOT waited for
