@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
 //    wave 64 contiguous bytes of each of its 32 rows.  Stored per lane these are 64 cache lines per instruction
 //    (measured: the stores then clog the memory pipe, +1.9 ms); they go through 2 KiB of wave-private LDS instead
 //    and leave row-major, 16 rows x 64 contiguous bytes per instruction;
-//    W chunk (pass, c) = 16 fragments [s][tile][lane] x 16 B = 16 KiB, 4-slot LDS ring filled by raw-buffer LDS-DMA
+//  * W chunk (pass, c) = 16 fragments [s][tile][lane] x 16 B = 16 KiB, 4-slot LDS ring filled by raw-buffer LDS-DMA
 //    (4 per wave and chunk).  The barrier at the top of chunk n publishes chunk n+1, so the first fragment group
 //    of a chunk is requested before the barrier that precedes it;
 //  * bias: the accumulators start at zero (first MFMA of a pass takes C = 0) and the pass epilogue adds the
