@@ -162,69 +162,80 @@ __global__ __launch_bounds__(256) void k_sgemm_nn(SgArgs a)
     }
 }
 
-// ---- TN: wave tile 128 x 128 (4 x 4 interleaved tiles: rows n0 + 4i + qm, columns k0 + 4j + qn);
-// grid (ceil(K/128), ceil(N/128), taps)
-__global__ __launch_bounds__(256, 1) void k_sgemm_tn(SgArgs a)
+// ---- TN: workgroup tile 128 x 128, wave (wy, wx) owns the 64 x 64 quarter (2 x 2 interleaved tiles: rows
+// n0 + 64wy + 2i + qm, columns k0 + 64wx + 2j + qn) and walks the WHOLE contraction range of the split by itself: no
+// barrier, no LDS, 64 accumulator registers, the operands of its next four steps in flight.  (Round 2's form — one wave
+// = the whole 128 x 128 tile, the four waves splitting the contraction, a 3-round LDS reduction at the end — was one wave
+// per SIMD with one step of operands in flight: it waited out a memory round trip per 16 MFMAs, 0.23 of the fp32 MFMA
+// peak at 6 432 rows.)  grid (ceil(K/128), ceil(N/128), taps x splits)
+__global__ __launch_bounds__(256) void k_sgemm_tn(SgArgs a)
 {
-    __shared__ float red[16 * 1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, half = lane >> 5;
+    const int wy = wave >> 1, wx = wave & 1;
     const int Mc = a.M, N = a.N, K = a.K;
-    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int k0 = blockIdx.x * 128 + 64 * wx, n0 = blockIdx.y * 128 + 64 * wy;
     const int ks_n = a.ksplit > 0 ? a.ksplit : 1;
     const int tap = blockIdx.z / ks_n, split = blockIdx.z - tap * ks_n;
-    const bool nok = n0 + 4 * i < N, kok = k0 + 4 * i < K;
-    const int ncol = nok ? n0 + 4 * i : N - 4, kcol = kok ? k0 + 4 * i : K - 4;
+    const bool nok = n0 + 2 * i < N, kok = k0 + 2 * i < K;  // N, K % 4 == 0: a pair exists or not as a whole
+    const int ncol = nok ? n0 + 2 * i : 0, kcol = kok ? k0 + 2 * i : 0;
     const int shift = tap - (a.taps - 1);
     const int steps_all = (Mc + 1) / 2;
     const int s_lo = (int)((long)steps_all * split / ks_n), s_hi = (int)((long)steps_all * (split + 1) / ks_n);
     const int steps = s_hi - s_lo;
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-    f32x16 acc[4][4];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int qm = 0; qm < 4; ++qm)
+    for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
-        for (int qn = 0; qn < 4; ++qn)
+        for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
 
-    struct Ops { f32x4 y, x; };
+    struct Ops { f32x2v y, x; };
     auto load = [&](Ops &o, int ks) {
         const int m = 2 * (s_lo + ks) + half;
         const bool mok = m < Mc;
         const int mm = mok ? m : Mc - 1;
         const bool xok = mok && (mm % a.seg) + shift >= 0;
-        o.y = *(const f32x4 *)(a.A + (long)mm * a.lda + ncol);
-        o.x = *(const f32x4 *)(a.B + (long)(xok ? mm + shift : mm) * a.ldb + kcol);
-        if (!xok) o.x = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!mok) o.y = f32x4{0.f, 0.f, 0.f, 0.f};
+        o.y = *(const f32x2v *)(a.A + (long)mm * a.lda + ncol);
+        o.x = *(const f32x2v *)(a.B + (long)(xok ? mm + shift : mm) * a.ldb + kcol);
+        if (!xok) o.x = f32x2v{0.f, 0.f};
+        if (!mok) o.y = f32x2v{0.f, 0.f};
     };
     auto compute = [&](const Ops &o) {
 #pragma unroll
-        for (int qm = 0; qm < 4; ++qm)
+        for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
-            for (int qn = 0; qn < 4; ++qn)
+            for (int qn = 0; qn < 2; ++qn)
                 acc[qm][qn] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.y[qm], o.x[qn], acc[qm][qn], 0, 0, 0);
     };
-    if (wave < steps) {
-        Ops cur, nxt;
-        load(cur, wave);
-        for (int ks = wave; ks < steps; ks += 4) {
-            if (ks + 4 < steps) load(nxt, ks + 4);
-            compute(cur);
-            cur = nxt;
-        }
-    }
-    reduce_to_wave0<16>(reinterpret_cast<f32x16(&)[16]>(acc), red, wave, lane);
-    if (wave != 0 || !kok) return;
+    {
+        Ops r[4];
 #pragma unroll
-    for (int qm = 0; qm < 4; ++qm)
+        for (int j = 0; j < 4; ++j) load(r[j], j < steps ? j : 0);
+        int ks = 0;
+        for (; ks + 4 <= steps; ks += 4) {  // whole groups of four: statically indexed ring
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                compute(r[j]);
+                load(r[j], ks + j + 4 < steps ? ks + j + 4 : steps - 1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (ks + j < steps) compute(r[j]);
+    }
+    if (!kok) return;
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = n0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * half) + qm;
+            const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + qm;
             if (n >= N) continue;
-            const f32x4 o = {acc[qm][0][r], acc[qm][1][r], acc[qm][2][r], acc[qm][3][r]};
-            *(f32x4 *)(a.C + (((long)split * a.taps + tap) * N + n) * a.ldc + kcol) = o;
+            const f32x2v o = {acc[qm][0][r], acc[qm][1][r]};
+            *(f32x2v *)(a.C + (((long)split * a.taps + tap) * N + n) * a.ldc + kcol) = o;
         }
 }
 
