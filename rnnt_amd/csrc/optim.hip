@@ -22,7 +22,7 @@
 #include "kernels.hpp"
 
 #define MT_MAX 40          // tensors per launch (kernel arguments stay under 4 KiB)
-#define MT_CHUNK 16384     // elements per workgroup
+#define MT_CHUNK 4096      // elements per workgroup
 #define MT_THREADS 256
 
 struct MtNormArgs {
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_sumsq(MtNormArgs a)
     float s = 0.f;
     if ((((uintptr_t)g) & 15) == 0) {
         const int n4 = cnt >> 2;
+#pragma unroll 4
         for (int i = threadIdx.x; i < n4; i += MT_THREADS) {
             const f32x4 x = ((const f32x4 *)g)[i];
             s += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
@@ -99,7 +100,9 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_norm_final(const float *__res
     if (threadIdx.x == 0) out[0] = (float)sqrt((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
-__device__ __forceinline__ void adamw_one(float &p, float &g, float &m, float &v, const MtAdamArgs &a, float coef)
+// the scalars of one update (kernel arguments or, capturable form, read from the device)
+struct AdamScalars { float decay, step_size, bc2_sqrt, omb1, beta2, omb2, eps; };
+__device__ __forceinline__ void adamw_one(float &p, float &g, float &m, float &v, const AdamScalars &a, float coef)
 {
     g *= coef;
     p *= a.decay;
@@ -122,12 +125,15 @@ __global__ void k_adam_prepare(long long *__restrict__ step, const float *__rest
     hyper[2] = (float)sqrt(1.0 - pow(beta2, (double)t));
 }
 
-__global__ __launch_bounds__(MT_THREADS) void k_mt_adamw(MtAdamArgs a)
+__global__ __launch_bounds__(MT_THREADS) void k_mt_adamw(const MtAdamArgs a)
 {
+    // (the argument block is only READ: writing the device-side scalars into it, as round 2 did, made hipcc copy all
+    // 1.8 KB of it into every thread's scratch — 470 KB of private-memory traffic per workgroup before the first load)
+    AdamScalars sc = {a.decay, a.step_size, a.bc2_sqrt, a.omb1, a.beta2, a.omb2, a.eps};
     if (a.dev_hyper) {  // workgroup-uniform
-        a.decay = a.dev_hyper[0];
-        a.step_size = a.dev_hyper[1];
-        a.bc2_sqrt = a.dev_hyper[2];
+        sc.decay = a.dev_hyper[0];
+        sc.step_size = a.dev_hyper[1];
+        sc.bc2_sqrt = a.dev_hyper[2];
     }
     const int t = mt_find(a, blockIdx.x);
     const long base = (long)(blockIdx.x - a.chunk0[t]) * MT_CHUNK;
@@ -145,22 +151,35 @@ __global__ __launch_bounds__(MT_THREADS) void k_mt_adamw(MtAdamArgs a)
     int done = 0;
     if (vec) {
         const int n4 = cnt >> 2;
-        for (int i = threadIdx.x; i < n4; i += MT_THREADS) {
-            f32x4 P = ((f32x4 *)p)[i], G = ((const f32x4 *)g)[i], M = ((f32x4 *)m)[i], V = ((f32x4 *)v)[i];
+        auto one = [&](int i, f32x4 P, f32x4 G, f32x4 M, f32x4 V) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float pq = P[q], gq = G[q], mq = M[q], vq = V[q];
-                adamw_one(pq, gq, mq, vq, a, coef);
+                adamw_one(pq, gq, mq, vq, sc, coef);
                 P[q] = pq; G[q] = gq; M[q] = mq; V[q] = vq;
             }
             ((f32x4 *)p)[i] = P; ((f32x4 *)m)[i] = M; ((f32x4 *)v)[i] = V;
             if (wg) ((f32x4 *)const_cast<float *>(g))[i] = G;
+        };
+        // four quads per thread and trip, all 16 loads requested before the first is used (one quad per trip left the
+        // kernel waiting out a memory round trip per 64 bytes and thread: 1.5 TB/s)
+        int i = threadIdx.x;
+        for (; i + 3 * MT_THREADS < n4; i += 4 * MT_THREADS) {
+            f32x4 P[4], G[4], M[4], V[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ik = i + k * MT_THREADS;
+                P[k] = ((f32x4 *)p)[ik]; G[k] = ((const f32x4 *)g)[ik]; M[k] = ((f32x4 *)m)[ik]; V[k] = ((f32x4 *)v)[ik];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) one(i + k * MT_THREADS, P[k], G[k], M[k], V[k]);
         }
+        for (; i < n4; i += MT_THREADS) one(i, ((f32x4 *)p)[i], ((const f32x4 *)g)[i], ((f32x4 *)m)[i], ((f32x4 *)v)[i]);
         done = n4 << 2;
     }
     for (int i = done + threadIdx.x; i < cnt; i += MT_THREADS) {
         float P = p[i], G = g[i], M = m[i], V = v[i];
-        adamw_one(P, G, M, V, a, coef);
+        adamw_one(P, G, M, V, sc, coef);
         p[i] = P; m[i] = M; v[i] = V;
         if (wg) const_cast<float *>(g)[i] = G;
     }
