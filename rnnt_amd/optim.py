@@ -23,7 +23,7 @@ import torch
 
 from . import engine
 
-__all__ = ["AdamW", "clip_grad_norm_"]
+__all__ = ["AdamW", "clip_grad_norm_", "BucketGradNorm"]
 
 
 def _ptr_array(tensors: List[torch.Tensor]):
@@ -77,6 +77,50 @@ def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float) -> torc
     return total
 
 
+class BucketGradNorm:
+    """The gradient norm of a DDP model, accumulated bucket by bucket as the all-reduces complete — the pass over
+    the gradients that `clip_grad_norm_` (rnnt/train.py:136) makes after backward then overlaps the remaining
+    all-reduces and the rest of backward (the reference wraps the model in DDP, rnnt/train.py:68, and steps at :164).
+
+        norm = rnnt_amd.optim.BucketGradNorm(ddp_model)                  # registers a DDP communication hook
+        optimizer = rnnt_amd.optim.AdamW(params, ..., max_grad_norm=clip, norm_source=norm)
+        loss.backward(); optimizer.step()                                # no separate norm pass
+
+    The hook does what DDP's default one does (divide the bucket by the world size, all-reduce it) and, chained to
+    that, one engine norm kernel on the reduced bucket on the stream the all-reduce completed on.  `total()` returns
+    sqrt(sum of the buckets' squared norms) as a 0-dim device tensor (no host sync) and starts the next iteration.
+    Every parameter with a gradient lives in exactly one bucket, so this is the norm `clip_grad_norm_` computes."""
+
+    def __init__(self, ddp_model, process_group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.process_group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self._parts: List[torch.Tensor] = []
+        ddp_model.register_comm_hook(self, BucketGradNorm._hook)
+
+    @staticmethod
+    def _hook(state, bucket):
+        buf = bucket.buffer()
+        buf.div_(state.world_size)
+        fut = state._dist.all_reduce(buf, group=state.process_group, async_op=True).get_future()
+
+        def reduced(f):
+            t = f.value()[0]
+            n = grad_norm([t])
+            state._parts.append(n * n)
+            return t
+
+        return fut.then(reduced)
+
+    def total(self) -> torch.Tensor:
+        """Norm over the buckets reduced since the last call (call once per iteration, after backward)."""
+        if not self._parts:
+            return torch.tensor(0.0)
+        parts, self._parts = self._parts, []
+        return torch.sqrt(torch.stack(parts).sum())
+
+
 class AdamW(torch.optim.Optimizer):
     """torch.optim.AdamW(params, lr, betas, eps, weight_decay) — decoupled weight decay, no amsgrad,
     no maximize — whose step() is one multi-tensor engine call per parameter group.
@@ -87,12 +131,14 @@ class AdamW(torch.optim.Optimizer):
     host.  `last_grad_norm` then holds the device scalar."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-                 max_grad_norm=None, capturable=False):
+                 max_grad_norm=None, capturable=False, norm_source=None):
         if float(lr) < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("rnnt_amd.optim.AdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.last_grad_norm = None
+        # optional BucketGradNorm: the norm was accumulated during backward, step() makes no pass of its own
+        self.norm_source = norm_source
         # capturable=True (as torch.optim.AdamW's flag): the step count and the learning rate live on the
         # device (rnnt_engine_adamw_step_dev) — nothing of an update is baked into the launches, so step()
         # can be captured into a HIP graph together with forward and backward.  group["lr"] becomes a
@@ -111,7 +157,10 @@ class AdamW(torch.optim.Optimizer):
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
             allg = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
             if allg:
-                total = grad_norm(allg)
+                total = self.norm_source.total().reshape(()) if self.norm_source is not None else grad_norm(allg)
+                if total.device != allg[0].device:  # (no bucket was reduced: nothing to clip)
+                    total = total.to(allg[0].device)
+                total = total.contiguous()
                 self.last_grad_norm = total
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]

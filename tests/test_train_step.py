@@ -336,3 +336,47 @@ def test_whole_training_step_as_one_hip_graph():
         assert abs(w - g_) <= 2e-5 * abs(w), (want, got)
     for (n, p), q in zip(model.named_parameters(), twin.parameters()):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.gpu
+def test_bucket_grad_norm_hook_matches_clip_grad_norm():
+    """rnnt_amd.optim.BucketGradNorm (the clip's norm overlapped with the DDP all-reduce): the norm
+    accumulated bucket by bucket in DDP's communication hook equals torch's clip_grad_norm_ total, the gradients are
+    what the default hook leaves, and AdamW(norm_source=...) steps like AdamW(max_grad_norm=...) with its own pass."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    import rnnt_amd
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group(backend="nccl")
+    try:
+        dev = torch.device("cuda:0")
+        torch.manual_seed(3)
+
+        def make():
+            torch.manual_seed(3)
+            return torch.nn.Sequential(torch.nn.Linear(300, 700), torch.nn.Tanh(), torch.nn.Linear(700, 1100), torch.nn.Tanh(),
+                                       torch.nn.Linear(1100, 64)).to(dev)
+
+        ma, mb = make(), make()
+        # small buckets: several all-reduces per backward
+        da, db = DDP(ma, device_ids=[0], bucket_cap_mb=1), DDP(mb, device_ids=[0], bucket_cap_mb=1)
+        norm = rnnt_amd.optim.BucketGradNorm(da)
+        oa = rnnt_amd.optim.AdamW(ma.parameters(), lr=1e-2, max_grad_norm=0.5, norm_source=norm)
+        ob = rnnt_amd.optim.AdamW(mb.parameters(), lr=1e-2, max_grad_norm=0.5)
+        x = torch.randn(32, 300, device=dev)
+        for it in range(3):
+            for d, o in ((da, oa), (db, ob)):
+                o.zero_grad(set_to_none=True)
+                (d(x) ** 2).sum().backward()
+            ref = torch.nn.utils.clip_grad_norm_(list(mb.parameters()), 1e9)  # the norm only: the coefficient clamps to 1
+            for pa, pb in zip(ma.parameters(), mb.parameters()):
+                assert torch.equal(pa.grad, pb.grad)
+            oa.step(); ob.step()
+            assert abs(oa.last_grad_norm.item() - ref.item()) <= 2e-6 * ref.item(), (it, oa.last_grad_norm.item(), ref.item())
+            assert abs(ob.last_grad_norm.item() - ref.item()) <= 2e-6 * ref.item()
+            for pa, pb in zip(ma.parameters(), mb.parameters()):
+                assert torch.allclose(pa, pb, rtol=0, atol=2e-7), it
+    finally:
+        dist.destroy_process_group()
