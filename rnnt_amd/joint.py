@@ -25,12 +25,15 @@ class JointNetwork(torch.nn.Module):
         self.joint_ln = torch.nn.Linear(hidden_features, num_classes)
         self.blank_idx = num_classes - 1
 
-    @staticmethod
-    def _linear(layer, x):
-        # HIP tensors with MFMA-friendly sizes go through the engine's small-GEMM kernels (forward
-        # and backward: rnnt_engine_linear_fwd / _bwd); anything else (CPU
-        # export, odd feature sizes) is torch's own Linear
-        if (x.is_cuda and x.dtype == torch.float32 and layer.in_features % 4 == 0
+    # The optional input projections are plain GEMMs ([B*T, Fa] x [Fa, H]: 32 000 rows at the headline config).
+    # "library": torch.nn.functional.linear, i.e. rocBLAS / hipBLASLt — ahead of the engine's small-GEMM kernels at every
+    # size measured (tools/bench_linear.py: 0.18 vs 0.23 ms at 808 rows, 1.46 vs 2.36 ms at 32 000, forward + backward),
+    # so it is the default; "engine": rnnt_engine_linear_fwd / _bwd (the C ABI's own path for
+    # callers without torch, kept under test through this switch).
+    projection_backend = "library"
+
+    def _linear(self, layer, x):
+        if (self.projection_backend == "engine" and x.is_cuda and x.dtype == torch.float32 and layer.in_features % 4 == 0
                 and layer.out_features % 4 == 0 and not torch.jit.is_tracing()):
             return F_amd.linear(x, layer.weight, layer.bias)
         return layer(x)

@@ -269,12 +269,15 @@ def _sd(z):
     return {k[4:].replace("__", "."): torch.from_numpy(z[k]) for k in z.files if k.startswith("sd__")}
 
 
-@pytest.mark.parametrize("name", ["joint_tiny", "joint_mid", "joint_proj", "joint_v1024"])
-def test_joint_forward_golden(amd, golden_dir, name):
+@pytest.mark.parametrize("name,backend", [("joint_tiny", "library"), ("joint_mid", "library"), ("joint_proj", "library"),
+                                          ("joint_proj", "engine"), ("joint_v1024", "library")])
+def test_joint_forward_golden(amd, golden_dir, name, backend):
     """JointNetwork.forward on the engine vs logits/grads produced by the reference's own
-    rnnt.joint.JointNetwork (tests/golden/make_golden.py)."""
+    rnnt.joint.JointNetwork (tests/golden/make_golden.py); the input projections through the library GEMM (the
+    default) and through the engine's own linear kernels."""
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     m = amd.JointNetwork(*[int(x) for x in z["ctor"]]).cuda()
+    m.projection_backend = backend
     m.load_state_dict(_sd(z))
     a = torch.from_numpy(z["audio"]).cuda().requires_grad_(True)
     t = torch.from_numpy(z["text"]).cuda().requires_grad_(True)
@@ -287,12 +290,14 @@ def test_joint_forward_golden(amd, golden_dir, name):
         assert_close_grad(k, p.grad.cpu().numpy(), z["grad__" + k.replace(".", "__")])
 
 
-@pytest.mark.parametrize("name", ["e2e_tiny", "e2e_mid", "e2e_proj", "e2e_v1024"])
-def test_fused_golden(amd, golden_dir, name):
+@pytest.mark.parametrize("name,backend", [("e2e_tiny", "library"), ("e2e_mid", "library"), ("e2e_proj", "library"),
+                                          ("e2e_proj", "engine"), ("e2e_v1024", "library")])
+def test_fused_golden(amd, golden_dir, name, backend):
     """fused_loss (joint + loss + backward in one engine call) vs the golden end-to-end
     fixtures (reference JointNetwork in fp64 + independent autograd loss)."""
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     m = amd.JointNetwork(*[int(x) for x in z["ctor"]]).cuda()
+    m.projection_backend = backend
     m.load_state_dict(_sd(z))
     a = torch.from_numpy(z["audio"]).cuda().requires_grad_(True)
     t = torch.from_numpy(z["text"]).cuda().requires_grad_(True)

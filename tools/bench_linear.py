@@ -1,0 +1,32 @@
+"""The joint's input projections (audio_ln / text_ln, reference rnnt/joint.py:8-12,26-30): engine small-GEMM kernels
+vs torch.nn.functional.linear (rocBLAS / hipBLASLt), forward + backward.   python tools/bench_linear.py [MxKxN ...]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rnnt_amd import functional as F_amd
+
+def timeit(f, n=20):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(808, 1024, 1024), (6432, 1024, 1024), (8000, 512, 1024), (32000, 512, 1024), (32000, 1024, 1024)]
+for M, K, N in SIZES:
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    W = (torch.randn(N, K, device="cuda") * 0.02).requires_grad_()
+    b = torch.zeros(N, device="cuda", requires_grad=True)
+    g = torch.randn(M, N, device="cuda")
+    res = {}
+    for name, fn in (("engine", F_amd.linear), ("torch", torch.nn.functional.linear)):
+        def step():
+            x.grad = W.grad = b.grad = None
+            fn(x, W, b).backward(g)
+        res[name] = timeit(step)
+        with torch.no_grad():
+            res[name + "_fwd"] = timeit(lambda: fn(x, W, b))
+    print(f"M={M} K={K} N={N}: engine fwd+bwd {res['engine']:.3f} ms (fwd {res['engine_fwd']:.3f}), torch {res['torch']:.3f} ms (fwd {res['torch_fwd']:.3f}); "
+          f"{6 * M * K * N / 1e9:.1f} GFLOP", flush=True)
