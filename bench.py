@@ -210,6 +210,8 @@ def main():
                          "(rnnt/model.py:27-28); the engine's tiled transpose is then part of every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true",
+                    help="skip the secondary `exact_fp32` object (the exact-fp32 MFMA route timed in the same run)")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the down-scaled parity twin of the CPU leg (it also goes with --no-cpu-baseline)")
     args = ap.parse_args()
@@ -307,7 +309,9 @@ def main():
     if not args.no_stage_timing:
         names = ["producers_hidden_wpack", "joint_fwd_gemm", "lattice_sweep", "grad_coef_make_g",
                  "dhidden_gemm", "dhidden_reduce", "dw_gemm", "dw_reduce"]
-        reps = max(2, min(args.steps, 5))
+        # as many repetitions per stage as timed steps (default 20): the three GEMM stages then keep the GPU busy
+        # for seconds, long enough for an external utilisation sampler to see the run
+        reps = max(2, args.steps)
         stage_ms = {}
         for s, name in enumerate(names):
             engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s,
@@ -319,6 +323,28 @@ def main():
                                           dtype=args.dtype)
             e1.record(); e1.synchronize()
             stage_ms[name] = e0.elapsed_time(e1) / reps
+
+    # ---- the exact-fp32 route (v_mfma_f32_32x32x2_f32: fp32 products, not split operands) timed in the same run, so
+    # that one driver-run line carries both arithmetic forms of the fp32-accurate path (N = 1, default route only)
+    exact_fp32 = None
+    if world == 1 and args.dtype == "bf16x3" and not args.no_exact_fp32:
+        n32 = max(3, args.steps // 2)
+        for _ in range(2):
+            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, dtype="fp32")
+        ev32 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n32)]
+        for e0, e1 in ev32:
+            e0.record()
+            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, dtype="fp32")
+            e1.record()
+        torch.cuda.synchronize()
+        t32 = sorted(e0.elapsed_time(e1) for e0, e1 in ev32)
+        m32 = t32[len(t32) // 2]
+        tf32 = 6.0 * H * V * Bl * T * (U + 1) / (m32 * 1e-3) / 1e12
+        exact_fp32 = {"ms_per_step": m32, "value": B * T * U / (m32 * 1e-3), "unit": "cells/s", "steps": n32,
+                      "arith": "v_mfma_f32_32x32x2_f32 (exact fp32 products)", "path_tflops": tf32,
+                      "peak": PEAK_F32_MFMA_TFLOPS, "frac": tf32 / PEAK_F32_MFMA_TFLOPS,
+                      "loss": float(costs.double().sum().item() * scale),
+                      "timing": f"hipEventElapsedTime per step, median of {n32}, same process and inputs as the headline"}
 
     if rank != 0:
         if dist_on:
@@ -355,7 +381,9 @@ def main():
         "loss": loss,
         # what actually ran: devices the runtime sees, ranks in the RCCL communicator
         "hipGetDeviceCount": torch.cuda.device_count(),
-        "rccl_ranks": dist.get_world_size() if dist_on else 0,
+        # ranks of the process group, under the name of the transport that carried the all-reduce: `rccl_ranks` only
+        # when the backend is nccl (= RCCL), `dist_ranks` for a gloo rehearsal
+        ("rccl_ranks" if (dist_on and backend == "nccl") or not dist_on else "dist_ranks"): dist.get_world_size() if dist_on else 0,
         "dist_backend": (("rccl" if backend == "nccl" else backend) if dist_on else None),  # "nccl" is RCCL on ROCm; gloo only in rehearsals
         "allreduce_via": ("rnnt_engine_allreduce" if comm is not None else "torch.distributed") if dist_on else None,
     }
@@ -395,6 +423,11 @@ def main():
                 # REPLAYED from the committed PMC profile of this config, not measured in this run
                 out["roofline"]["traffic_source"] = {"file": "profiles/" + tfile, "replayed": True,
                                                      "commit": tr.get("commit") or json.load(open(os.path.join(ROOT, "profiles", tfile))).get("commit")}
+                if tr.get("mfma_busy") is not None:
+                    # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of this kernel in the committed SQ
+                    # counter pass — REPLAYED like `traffic`, not measured in this run
+                    out["roofline"]["mfma_busy"] = tr["mfma_busy"]
+                    out["roofline"]["mfma_busy_source"] = {"file": tr.get("mfma_busy_file"), "replayed": True}
                 out["roofline"]["traffic_note"] = ("bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 PMC, separate "
                                                    "passes, KB x 1024; gfx950 half-count correction for 16 B/lane loads), "
                                                    "profiles/%s; algorithmic HBM bytes %.3g" % (tfile, tr["algorithmic"]))
@@ -405,6 +438,8 @@ def main():
         out["lattice_sweep"] = {"achieved_GBs": sweep_bytes / (stage_ms["lattice_sweep"] * 1e-3) / 1e9,
                                 "peak_GBs": PEAK_HBM_GBS, "bytes": sweep_bytes,
                                 "frac": sweep_bytes / (stage_ms["lattice_sweep"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if exact_fp32 is not None:
+        out["exact_fp32"] = exact_fp32
     if world == 1 and not args.no_cpu_baseline:
         # the CPU leg (rank 0, N = 1 only; the one place bench.py touches oracle/): the oracle as checker of a
         # down-scaled twin of the workload, then the CPU port timed on this box's host cores

@@ -91,12 +91,16 @@ class BucketGradNorm:
     sqrt(sum of the buckets' squared norms) as a 0-dim device tensor (no host sync) and starts the next iteration.
     Every parameter with a gradient lives in exactly one bucket, so this is the norm `clip_grad_norm_` computes."""
 
-    def __init__(self, ddp_model, process_group=None):
+    def __init__(self, ddp_model, process_group=None, norm_fn=None):
         import torch.distributed as dist
         self._dist = dist
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group)
         self._parts: List[torch.Tensor] = []
+        # the norm of one reduced bucket: the engine's kernel (HIP tensors only — it raises on anything else).
+        # `norm_fn` exists for the world-2 gloo test of the hook's arithmetic (tests/test_dist_cpu.py), where
+        # the buckets are CPU tensors; nothing in the package passes it.
+        self._norm = norm_fn if norm_fn is not None else (lambda t: grad_norm([t]))
         ddp_model.register_comm_hook(self, BucketGradNorm._hook)
 
     @staticmethod
@@ -107,7 +111,7 @@ class BucketGradNorm:
 
         def reduced(f):
             t = f.value()[0]
-            n = grad_norm([t])
+            n = state._norm(t)
             state._parts.append(n * n)
             return t
 

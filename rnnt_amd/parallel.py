@@ -72,9 +72,24 @@ class RcclComm:
         self._rccl = ctypes.CDLL(path if os.path.exists(path) else "librccl.so.1")
         self._rccl.ncclGetErrorString.restype = ctypes.c_char_p
         uid = _UniqueId()
-        if rank == 0:
+
+        def draw():
             self._ok(self._rccl.ncclGetUniqueId(ctypes.byref(uid)))
-        raw = bytes(uid) if rank == 0 else None  # all 128 bytes (not a C string)
+            return bytes(uid)  # all 128 bytes (not a C string)
+
+        raw = RcclComm.share_unique_id(rank, world, draw, exchange)
+        ctypes.memmove(ctypes.byref(uid), raw, 128)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._ok(self._rccl.ncclCommInitRank(ctypes.byref(self._comm), ctypes.c_int(world), uid, ctypes.c_int(rank)))
+
+    @staticmethod
+    def share_unique_id(rank: int, world: int, draw, exchange=None) -> bytes:
+        """The id hand-round of the constructor, on its own (tests/test_dist_cpu.py runs it with two gloo ranks):
+        rank 0 calls `draw()` for the 128 bytes of an ncclUniqueId, `exchange(bytes or None) -> bytes` carries them to
+        every rank (default: torch.distributed.broadcast_object_list on the default group), and every rank returns
+        the same 128 bytes — embedded zero bytes included; anything else raises."""
+        raw = draw() if rank == 0 else None
         if world > 1:
             if exchange is None:
                 import torch.distributed as dist
@@ -84,10 +99,10 @@ class RcclComm:
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
             raw = exchange(raw)
-        ctypes.memmove(ctypes.byref(uid), raw, 128)
-        self._comm = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            self._ok(self._rccl.ncclCommInitRank(ctypes.byref(self._comm), ctypes.c_int(world), uid, ctypes.c_int(rank)))
+        if not isinstance(raw, (bytes, bytearray)) or len(raw) != 128:
+            raise RuntimeError(f"RcclComm: the unique id must arrive as 128 bytes on every rank (rank {rank} got "
+                               f"{type(raw).__name__} of length {len(raw) if hasattr(raw, '__len__') else '?'})")
+        return bytes(raw)
 
     def _ok(self, rc):
         if rc != 0:

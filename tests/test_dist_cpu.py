@@ -69,3 +69,63 @@ def test_shard_bounds_cover_batch():
             spans = [shard_bounds(B, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+# ---- BucketGradNorm's communication hook and RcclComm's id hand-round with two real ranks (gloo)
+def _hook_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rnnt_amd.optim import BucketGradNorm
+    from rnnt_amd.parallel import RcclComm
+    torch.manual_seed(0)  # identical replicas
+    def make():
+        return torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.Tanh(), torch.nn.Linear(64, 48), torch.nn.Tanh(),
+                                   torch.nn.Linear(48, 5))
+    net, twin = make(), make()
+    twin.load_state_dict(net.state_dict())
+    # tiny buckets: several all-reduces per backward, so the total really is a sum over buckets
+    ddp = torch.nn.parallel.DistributedDataParallel(net, bucket_cap_mb=0.004)
+    ref = torch.nn.parallel.DistributedDataParallel(twin, bucket_cap_mb=0.004)  # DDP's default hook
+    norm = BucketGradNorm(ddp, norm_fn=lambda t: torch.linalg.vector_norm(t.double()).float())
+    g = torch.Generator().manual_seed(100 + rank)  # every rank its own shard
+    totals, nbuckets = [], []
+    for it in range(3):
+        x = torch.randn(6, 37, generator=g); y = torch.randn(6, 5, generator=g)
+        for m in (ddp, ref):
+            m.zero_grad()
+            ((m(x) - y) ** 2).mean().backward()
+        nbuckets.append(len(norm._parts))
+        total = norm.total()
+        want = torch.nn.utils.clip_grad_norm_(ref.parameters(), 1e9)  # the global norm of the averaged gradients
+        totals.append((float(total), float(want)))
+        for p, q in zip(ddp.parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad)  # the hook reduces exactly as the default one does
+        assert norm._parts == []  # total() starts the next iteration
+    # RcclComm's id hand-round: rank 0 draws 128 bytes with zero bytes inside, every rank must hold the same 128
+    drawn = bytes([7, 0, 0, 9] + list(range(124)))
+    calls = []
+    uid = RcclComm.share_unique_id(rank, world, lambda: calls.append(1) or drawn)
+    assert uid == drawn and len(calls) == (1 if rank == 0 else 0)
+    # an exchange that truncates at the first zero byte (a C-string hand-over) must be refused, not joined with
+    try:
+        RcclComm.share_unique_id(rank, world, lambda: drawn, exchange=lambda b: drawn.split(b"\0")[0])
+        bad = False
+    except RuntimeError:
+        bad = True
+    assert bad
+    if rank == 0:
+        np.savez(out, totals=np.array(totals), nbuckets=np.array(nbuckets))
+    dist.destroy_process_group()
+
+
+def test_bucket_grad_norm_hook_and_unique_id_exchange_two_ranks(tmp_path):
+    """world_size 2, gloo: sqrt(sum of the buckets' norms^2) of BucketGradNorm's hook == the global norm
+    clip_grad_norm_ computes on a twin under DDP's default hook (gradients bit-identical), over several
+    iterations and several buckets per backward; RcclComm.share_unique_id hands rank 0's 128 bytes round intact."""
+    out = str(tmp_path / "hook.npz")
+    mp.spawn(_hook_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    z = np.load(out)
+    assert (z["nbuckets"][1:] >= 2).all(), z["nbuckets"]  # (DDP lays its buckets out for good after the first backward)
+    for got, want in z["totals"]:
+        assert want > 0 and abs(got - want) <= 1e-6 * want, (got, want)
