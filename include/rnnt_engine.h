@@ -82,6 +82,13 @@ void rnnt_engine_set_debug(void *buf);
  * NOT bit-identical to the default bf16x3 kernels (different summation), same tolerance. */
 #define RNNT_VARIANT_X3_FP32_FWD 4096       /* forward GEMM + hidden by the fp32 kernel, then k_x3_make_hidden */
 #define RNNT_VARIANT_X3_FP32_DH 8192        /* dHidden + G by the fp32 kernels, then k_x3_split_g (needs _FWD too) */
+/* RNNT_DTYPE_F32_BF16X3 only: the forward in its two-waves-per-SIMD forms (k_joint_fwd_x3d, round 4: each wave owns 32
+ * rows x 256 columns, the A operand never leaves its registers) instead of the default k_joint_fwd_x3 (one 512-register
+ * wave per SIMD).  Measured SLOWER than the default: kept as the record of that experiment and as a
+ * second, independently written forward that tests compare.  Same products, different summation order inside a dot
+ * product: same tolerance, not bit-identical. */
+#define RNNT_VARIANT_X3_FWD_2WG 16384       /* two 4-wave workgroups per CU, 128-cell tiles */
+#define RNNT_VARIANT_X3_FWD_8W 65536        /* one 8-wave workgroup per CU, 256-cell tiles */
 
 /* Diagnostic queries (0/1: predicted resident forward-kernel workgroups per CU). */
 int rnnt_engine_debug_query(int what);

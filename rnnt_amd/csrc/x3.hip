@@ -916,6 +916,369 @@ void launch_joint_fwd_x3(const X3Args &a, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------
+// k_joint_fwd_x3d (round 4): the forward in the form the round-3 measurements named — TWO workgroups per CU that
+// share no barrier, so that whatever one wave of a SIMD waits for (its workgroup's barrier, a counted vmcnt, the
+// ~100 cycles an LDS-DMA issue blocks the issuing wave) the SIMD's other wave, from the other workgroup, keeps the
+// matrix pipe fed.  (k_joint_fwd_x3 above — one 512-register wave per SIMD — measured 22 ms of MFMA stream and
+// 24 ms of skeleton that ADD to 34 instead of overlapping.)
+//  * workgroup = 4 waves, tile = 128 consecutive cells, pass = 256 logits columns; wave w owns rows 32w .. 32w+31
+//    of the tile for ALL 256 columns of the pass: one M tile x 8 N tiles = 128 accumulator registers, 256
+//    registers per wave in all -> two waves per SIMD;
+//  * A never touches LDS: lane (i, half) of wave w produces tanh(enc + pred) of ITS fragment slot (row 32w + i,
+//    k = 16c + 8 half ..) one k-step ahead, splits it and keeps the three planes in 12 registers (first pass:
+//    also stored for k_dw_x3) — no exchange ring, no ds_write, nothing of A behind the barrier;
+//  * W k-steps (3 planes x 8 tiles = 24 KiB: the existing pack, half a 512-column pass at a time) by LDS-DMA into
+//    a 3-slot ring, 6 pieces per wave, requested TWO k-steps ahead; one barrier per k-step publishes a slot;
+//  * per tile q: 3 fragment reads (hi, mid, lo of W tile q, issued during tile q-1's MFMAs) feed 6 MFMAs on one
+//    accumulator tile (a dependent chain of v_mfma_f32_32x32x16_bf16 issues back to back: MI355X_MICROARCH.md);
+//  * DMA issues, operand loads, the 16 production pieces and the hidden stores ride between the 48 MFMAs of a
+//    k-step; memory operations are unconditional and in one fixed order per k-step (D x6, L x4, S x3) so that
+//    every vmcnt is a count;
+//  * pass end, statistics, finalisation: as k_joint_fwd_x3 (a row's 256 columns of a pass now sit in ONE wave).
+// Persistent workgroups, 2 per CU (75 KiB of LDS each), tiles from one atomic counter.  H % 32 == 0 (k loop
+// unrolled by 2), V % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define XD_WSLOT 24576
+#define XD_NSLOT 3
+// NW = waves per workgroup = 32-row M tiles per tile.  4: two workgroups per CU that share nothing; 8: ONE workgroup per CU,
+// two waves per SIMD that share the W ring — half the W bytes staged per MFMA (a 256-cell tile per 24 KiB k-step).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_joint_fwd_x3d(X3Args a, const int ntiles)
+{
+    constexpr int ROWS = 32 * NW, ND = 24 / NW;  // tile rows; W DMA pieces per wave and k-step
+    // [0, 72 KiB): W ring;  then: s_den[128], s_part[128][2], s_next[2]
+    extern __shared__ __attribute__((aligned(1024))) char s_fd[];
+    float *s_den = (float *)(s_fd + XD_NSLOT * XD_WSLOT);
+    float *s_part = s_den + ROWS;  // [row][max, sum]
+    int *s_next = (int *)(s_part + 2 * ROWS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int H = a.H, V = a.V, KC = H / 16, U1 = a.U1, T = a.T;
+    const int npass = (V + 255) / 256;
+    const int NS = npass * KC;  // k-steps of a tile
+    const long cells = (long)a.B * T * U1;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+
+    const int lds0 = (int)(size_t)(lds_vptr)s_fd;
+    const int wb = lds0 + 16 * lane;  // W read: tile q of plane p of ring slot s at wb + s * XD_WSLOT + p * 8192 + q * 1024
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, ((V + 511) / 512) * KC * 49152, 0x00020000);
+    const int wvo = lane * 16;
+
+    if (X3_OFF(16384) && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // experiment: static priority for the younger half
+    if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    int tile = s_next[0];
+    for (int it = 1; tile < ntiles; ++it) {
+        if (tid == 0) s_next[it & 1] = (int)atomicAdd(a.counter, 1u);
+        const long row0 = (long)tile * ROWS;
+        if (tid < ROWS) { s_part[2 * tid] = RNNT_NEG_INF; s_part[2 * tid + 1] = 0.f; }
+        __syncthreads();  // s_next, s_part visible; every wave is past the previous tile's LDS reads
+        const int next = s_next[it & 1];
+        bool dead;  // a tile entirely in the time steps past one utterance's length: hidden rows only (k_joint_fwd_x3)
+        {
+            const long per = (long)T * U1, c_last = row0 + ROWS - 1;
+            const long b_first = row0 / per;
+            dead = c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T);
+        }
+        const long prow = row0 + 32 * wave + i;
+        const bool wave_rows_exist = row0 + 32 * wave < a.rows_alloc;  // wave-uniform
+        const long pc_ = prow < cells ? prow : cells - 1;  // rows past the lattice (last tile): the last cell again, same bits to the same place
+        const int pu = (int)(pc_ % U1);
+        const long pbt = pc_ / U1;
+        const int pt = (int)(pbt % T), pb = (int)(pbt / T);
+        const float *ep = a.enc + (long)pb * a.enc_sb + (long)pt * a.enc_st + 8 * half;
+        const float *pp = a.pred + ((long)pb * U1 + pu) * H + 8 * half;
+        u32x4 *hdst = (u32x4 *)a.hidden + pc_ * (H / 8) + half;  // + 2c: this lane's 16 bytes of k-step c; planes `ps` apart
+        const long ps = a.plane_stride / 8;
+        struct Opd { f32x4 e0, e1, p0, p1; };
+        struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm, pl; };
+        bool cs_started = false;  // (experiment switch 8192 only)
+        auto hstore = [&](u32x4 *p, const u32x4 &v) {  // hidden planes: streamed once, read by k_dw_x3 much later
+            if (X3_OFF(4096)) __builtin_nontemporal_store(v, p);  // experiment: measured SLOWER (nw8 37.8 vs 34.9 ms, nw4 35.7 vs 34.6)
+            else *p = v;
+        };
+        auto op_load1 = [&](Opd &o, int kcs, int k) {  // one of the four operand loads of k index kcs
+            if (X3_OFF(8192)) {  // experiment: no operand loads in the loop (the first k-step's values again; NOT a valid build)
+                if (cs_started) { asm volatile("" : "+v"(o.e0), "+v"(o.e1), "+v"(o.p0), "+v"(o.p1)); return; }
+            }
+            if (k == 0) o.e0 = *(const f32x4 *)(ep + 16 * kcs);
+            else if (k == 1) o.e1 = *(const f32x4 *)(ep + 16 * kcs + 4);
+            else if (k == 2) o.p0 = *(const f32x4 *)(pp + 16 * kcs);
+            else o.p1 = *(const f32x4 *)(pp + 16 * kcs + 4);
+        };
+        // pieces 0-7: tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 3-way split
+        auto prod_piece = [&](Prod &P, const Opd &o, int k) {
+            if (k < 8) {
+                const int j = k >> 1;
+                if (!(k & 1)) {
+                    const f32x4 &e = j < 2 ? o.e0 : o.e1, &pv = j < 2 ? o.p0 : o.p1;
+                    const int q = 2 * (j & 1);
+                    const f2 x = {e[q] + pv[q], e[q + 1] + pv[q + 1]};
+                    const f2 av = x * (2.0f * RNNT_LOG2E);
+                    P.w[j] = f2{__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+                } else {
+                    const f2 ex = P.w[j] + 1.0f;
+                    const f2 rr = {__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+                    P.w[j] = 1.0f - 2.0f * rr;
+                }
+            } else {
+                const int j = (k - 8) >> 1;
+                if (!(k & 1)) {
+                    const unsigned hh = x3_pack(P.w[j][0], P.w[j][1]);
+                    P.ph[j] = hh;
+                    P.ra = P.w[j][0] - x3_lo(hh); P.rb = P.w[j][1] - x3_hi(hh);
+                } else {
+                    const unsigned mm = x3_pack(P.ra, P.rb);
+                    P.pm[j] = mm;
+                    P.pl[j] = x3_pack(P.ra - x3_lo(mm), P.rb - x3_hi(mm));
+                }
+            }
+        };
+        // piece n (0..ND-1) of this wave's share of the W k-step at pack offset `base` -> ring slot `slot`
+        auto wdma = [&](int base, int slot, int n) {
+            if (X3_OFF(8)) return;
+            const int pc = wave * ND + n;  // 0..23: plane pc >> 3, tile pc & 7
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fd + slot * XD_WSLOT + pc * 1024), 16, wvo,
+                                                     base + (pc >> 3) * 16384 + (pc & 7) * 1024, 0, 0);
+        };
+        // pack offset of k-step (pass p, k index kc): [p >> 1][kc][plane][tile 8 (p & 1) + q]
+        auto wbase = [&](int p, int kc) { return ((p >> 1) * KC + kc) * 49152 + (p & 1) * 8192; };
+
+        if (dead) {
+            for (int kc = 0; kc < KC; ++kc) {
+                Opd o; Prod P;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) op_load1(o, kc, k);
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, pc);
+                if (!X3_OFF(128)) { hstore(hdst + 2 * kc, P.ph); hstore(hdst + 2 * kc + ps, P.pm); hstore(hdst + 2 * kc + 2 * ps, P.pl); }
+            }
+            tile = next;
+            continue;
+        }
+
+        f32x16 acc[8];
+        u32x4 Ah, Am, Al;  // the MFMA A fragment of the current k-step: this lane's slot of the three planes
+        Opd oset[2];       // operands of k-step cs+1 live in oset[(cs+1) & 1] during k-step cs (KC even: k loop unrolled by 2)
+        // pipeline prologue: W of k-steps 0 and 1 by DMA; A of k-step 0 produced (and stored); operands of k-step 1
+        {
+#pragma unroll
+            for (int n = 0; n < ND; ++n) wdma(wbase(0, 0), 0, n);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) wdma(KC > 1 ? wbase(0, 1) : wbase(0, 0), 1, n);
+            Opd o; Prod P;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) op_load1(o, 0, k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) op_load1(oset[1], KC > 1 ? 1 : 0, k);
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, pc);
+            if (!X3_OFF(128)) { hstore(hdst, P.ph); hstore(hdst + ps, P.pm); hstore(hdst + 2 * ps, P.pl); }
+            Ah = P.ph; Am = P.pm; Al = P.pl;
+        }
+        int cs = 0, slot = 0;
+        if (X3_OFF(8192)) { cs_started = true; oset[0] = oset[1]; }
+        int pd = KC > 2 ? 0 : 1, kd = KC > 2 ? 2 : 0;  // (pass, k index) of k-step cs + 2, the one the DMAs of k-step cs fetch
+        if (pd >= npass) { pd = npass - 1; kd = KC - 1; }
+
+        auto run_pass = [&](auto store_c, const int pass) {
+          constexpr bool STORE = decltype(store_c)::value != 0;
+          {  // the bias of this lane's 2 x 4 adjacent columns of the pass rides in the accumulators' initial value
+            const int c0 = 256 * pass + 4 * i;
+            const f32x4 b0 = c0 < V ? *(const f32x4 *)(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = c0 + 128 < V ? *(const f32x4 *)(a.bias + c0 + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = q < 4 ? b0[q] : b1[q - 4];
+          }
+          for (int kc0 = 0; kc0 < KC; kc0 += 2)
+#pragma unroll
+          for (int par = 0; par < 2; ++par, ++cs) {
+            const int kc = kc0 + par;
+            // W of k-step cs (this wave's share) landed: its DMAs were issued during k-step cs-2.  vmcnt retires in order;
+            // younger than them: L x4 + S x3 of k-step cs-2 and D x ND + L x4 + S x3 of k-step cs-1 (S: first pass only).
+            // First k-step of a pass: also behind the previous pass's logits stores (and the tile prologue): drain.
+            if (kc == 0 || X3_OFF(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STORE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(14 + ND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + ND) : "memory");
+            x3_lds_barrier();  // publishes W slot of k-step cs; every wave is past its reads of k-step cs-1 (the slot the DMAs below refill)
+            const int ws = wb + slot * XD_WSLOT;
+            const int dslot = slot == 0 ? 2 : slot - 1;  // (cs + 2) % 3
+            const int dbase = wbase(pd, kd);
+            const int kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
+            const Opd &ocur = oset[(par + 1) & 1];  // operands of A's k-step cs+1 (requested during the previous k-step)
+            Opd &onext = oset[par & 1];             // refilled with those of k-step cs+2
+            Prod P;
+            u32x4 b0[3], b1[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[p]) : "v"(ws), "n"(p * 8192));
+            // the fillers between the 48 MFMAs of the k-step, by slot index s = 6 q + m
+            auto filler = [&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                if (s < 12) { if (!(s & 1) && (s >> 1) < ND) wdma(dbase, dslot, s >> 1); }  // D x ND: k-step cs+2
+                else if (s < 16) op_load1(onext, kcnn, s - 12);                          // L x4: operands of A's k-step cs+2
+                else if (s < 47) {
+                    if (!(s & 1)) prod_piece(P, ocur, (s - 16) >> 1);                    // A of k-step cs+1: pieces 0..15 at s = 16, 18 .. 46
+                    else if (s == 45 && STORE && !X3_OFF(128)) hstore(hdst + 2 * kcn, P.ph);  // S: hi plane (complete after piece 14)
+                } else if (STORE && !X3_OFF(128)) { hstore(hdst + 2 * kcn + ps, P.pm); hstore(hdst + 2 * kcn + 2 * ps, P.pl); }  // S x2
+            };
+            auto tile_q = [&](auto q_c, const u32x4 (&bc)[3], u32x4 (&bn)[3]) {
+                constexpr int q = decltype(q_c)::value;
+                if (q < 7) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[p]) : "v"(ws), "n"(p * 8192 + (q < 7 ? q + 1 : 0) * 1024));
+                }
+                if (!X3_OFF(1)) acc[q] = x3_mfma(Ah, bc[0], acc[q]);
+                filler(X3Int<6 * q + 0>{}); __builtin_amdgcn_sched_barrier(0);
+                if (!X3_OFF(1)) acc[q] = x3_mfma(Am, bc[0], acc[q]);
+                filler(X3Int<6 * q + 1>{}); __builtin_amdgcn_sched_barrier(0);
+                if (!X3_OFF(1)) acc[q] = x3_mfma(Al, bc[0], acc[q]);
+                filler(X3Int<6 * q + 2>{}); __builtin_amdgcn_sched_barrier(0);
+                if (!X3_OFF(1)) acc[q] = x3_mfma(Ah, bc[1], acc[q]);
+                filler(X3Int<6 * q + 3>{}); __builtin_amdgcn_sched_barrier(0);
+                if (!X3_OFF(1)) acc[q] = x3_mfma(Am, bc[1], acc[q]);
+                filler(X3Int<6 * q + 4>{}); __builtin_amdgcn_sched_barrier(0);
+                if (!X3_OFF(1)) acc[q] = x3_mfma(Ah, bc[2], acc[q]);
+                filler(X3Int<6 * q + 5>{}); __builtin_amdgcn_sched_barrier(0);
+                if (q < 7) {  // tile q+1's fragments (issued six MFMAs ago)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            tile_q(X3Int<0>{}, b0, b1); tile_q(X3Int<1>{}, b1, b0); tile_q(X3Int<2>{}, b0, b1); tile_q(X3Int<3>{}, b1, b0);
+            tile_q(X3Int<4>{}, b0, b1); tile_q(X3Int<5>{}, b1, b0); tile_q(X3Int<6>{}, b0, b1); tile_q(X3Int<7>{}, b1, b0);
+            Ah = P.ph; Am = P.pm; Al = P.pl;  // (the pass's last k-step produced — and re-stored — k-step 0 of the tile's rows)
+            slot = slot == 2 ? 0 : slot + 1;
+            if (++kd == KC) { kd = 0; ++pd; }
+            if (pd >= npass) { pd = npass - 1; kd = KC - 1; }  // past the tile's last k-step: a valid k-step again, into a slot nobody reads
+          }
+          // pass complete: store the logits, update the statistics (k_joint_fwd_x3's pass end for one M tile)
+          if (X3_OFF(16)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(acc[q]));
+          }
+          if (!X3_OFF(16)) {
+            const int cw = 256 * pass;
+            const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
+            char *tile_base = (char *)(a.logits + row0 * V + cw);
+            auto epilogue = [&](auto both_c) {
+                constexpr bool BOTH = decltype(both_c)::value != 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { o0[q] = acc[q][r]; o1[q] = acc[4 + q][r]; }
+                    char *rowp = tile_base + (long)(32 * wave + (r & 3) + 8 * (r >> 2)) * V * 4;  // wave-uniform
+                    // (the last tile's rows past the lattice: logits rows exist up to rows_alloc, a multiple of 128 — a 256-row
+                    // tile can reach beyond it, always by whole waves)
+                    if (!X3_OFF(2) && wave_rows_exist) {
+                        if (X3_OFF(1024)) {  // experiment: plain stores
+                            *(f32x4 *)(rowp + lane_off) = o0;
+                            if (BOTH) *(f32x4 *)(rowp + lane_off + 512) = o1;
+                        } else {
+                            __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
+                            if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
+                        }
+                        if (X3_OFF(2048)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // experiment: paced stores
+                    }
+                    if (!X3_OFF(32)) {
+                        float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
+                        if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                        const float M = half_max_dpp(m8, half);
+                        const float nm2 = -M * RNNT_LOG2E;
+                        float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                                  (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                        if (BOTH)
+                            e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                                 (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                        const float S_ = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
+                        if (i == 31) {
+                            float *sp = s_part + (32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
+                            const float m_o = sp[0], s_o = sp[1];
+                            const float mn = fmaxf(m_o, M);
+                            sp[0] = mn;
+                            sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
+                }
+            };
+            if (cw + 128 < V) epilogue(X3Int<1>{});
+            else epilogue(X3Int<0>{});
+          }
+        };
+        run_pass(X3Int<1>{}, 0);
+        for (int pass = 1; pass < npass; ++pass) run_pass(X3Int<0>{}, pass);
+
+        // ---- log-softmax denominators and the two log-probs of every lattice cell (as k_joint_fwd_x3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every logits / hidden store of the workgroup has left its wave; s_part complete; the over-issued DMAs landed
+        if (tid < ROWS) s_den[tid] = s_part[tid * 2] + __logf(s_part[tid * 2 + 1]);
+        __syncthreads();
+        {
+            const int row = tid & (ROWS - 1), which = tid / ROWS;
+            const long cell = row0 + row;
+            if (cell < cells) {
+                const int u = (int)(cell % U1);
+                const long bt = cell / U1;
+                const int t = (int)(bt % T), b = (int)(bt / T);
+                const int Ub = len_u(a.target_lens, b, U1);
+                if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
+                    const float den = s_den[row];
+                    const float *lrow = a.logits + cell * V;
+                    const long si = skew_index(b, t, u, a.D, U1);
+                    if (which == 0) {
+                        const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.denom_s[si] = den;
+                        a.lpb_s[si] = lb - den;
+                    } else {
+                        float le = 0.f;
+                        if (u < Ub) {
+                            const int y = a.targets[(long)b * (U1 - 1) + u];
+                            le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                        }
+                        a.lpe_s[si] = le;
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+}
+
+bool x3_fwd_d_ok(int U1, int H, int V) { return x3_fwd_ok(U1, H, V) && H % 32 == 0; }
+
+template <int NW>
+static void launch_joint_fwd_x3d_nw(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int rows = 32 * NW;
+    const int lds = XD_NSLOT * XD_WSLOT + rows * 4 + rows * 2 * 4 + 16;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_joint_fwd_x3d<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const long cells = (long)a.B * a.T * a.U1;
+    const int ntiles = (int)((cells + rows - 1) / rows);
+    launch_fill32(a.counter, 0u, 4, st);  // tile counter of the persistent workgroups
+    const int per_cu = NW == 4 ? 2 : 1;  // 256 registers per wave: two waves per SIMD either way
+    const int nwg = ntiles < per_cu * a.n_cu ? ntiles : per_cu * a.n_cu;
+    hipLaunchKernelGGL(k_joint_fwd_x3d<NW>, dim3((unsigned)nwg), dim3(64 * NW), lds, st, a, ntiles);
+}
+void launch_joint_fwd_x3d(const X3Args &a, int nw, hipStream_t st)
+{
+    if (nw == 8) launch_joint_fwd_x3d_nw<8>(a, st);
+    else launch_joint_fwd_x3d_nw<4>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------
 // W for the dHidden product, fragment order, three planes:
 //   [hp (512-column pass)][c (16-deep k-step = 16 vocabulary rows)][plane][tile(16)][lane] x 8 bf16,
 //   element j = piece_plane(W[v = 16c + 8*(lane>>5) + j][h = 512hp + 128*(tile>>2) + 4*(lane&31) + (tile&3)])
@@ -1035,6 +1398,43 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     u32x4 *ldst = (u32x4 *)(a.g_lo + pcell * V) + half;
     const u32x4 *lsrc = (const u32x4 *)(a.g_lo + (pexists ? pcell : zrow) * V) + half;
     const int blank = a.blank;
+    // G's hi | mid planes leave in WHOLE 128-byte lines (round 4): a line = the 32 x hi | 32 x mid of one cell and one
+    // 32-wide chunk = the fragments of two k-steps (c even, c odd) x two wave halves x two planes — eight 16-byte pieces
+    // that the producing wave reads back from ITS part of the LDS exchange (both slots hold the pair between the
+    // exchange write of the odd k-step and the next even one's) in row order: lane L -> row 8n + (L >> 3) of the M
+    // tile (n = 0..3: four store instructions, 8 whole lines each), piece L & 7 = (plane, k-step parity, half).
+    // (Producer-shaped stores wrote 32-byte pieces of these lines in four instructions a k-step apart: WRITE_SIZE
+    // 60.7 GB for 39.5 GB of G, profiles/r03_traffic.json.)  Raw-buffer stores over the tile's rows: rows outside the
+    // lattice get an offset past the range (dropped), so every wave issues the same store instructions.
+    const int lds0 = (int)(size_t)(lds_vptr)s_dh;
+    constexpr bool LINES = FIRST && !X3_OFF(32768);
+    constexpr bool LINES_LO = LINES && !X3_OFF(65536);  // the lo plane's half lines too
+    const int lpiece = lane & 7, lrow = lane >> 3;
+    // LDS: [slot = parity][M tile wave][plane][lane slot = row + 32 half]
+    const int xl = lds0 + 2 * XG_WSLOT + ((lpiece >> 1) & 1) * XG_XSLOT + wave * 3072 + (lpiece >> 2) * 1024 + 16 * (lrow + 32 * (lpiece & 1));
+    const long tile_cell0 = ((long)b * T + t0) * U1 + u0;  // the tile's first cell (exists: t0 < Tb <= T, u0 <= Ub < U1)
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.logits + tile_cell0 * V), 0, (int)((((long)(XG_BT - 1) * U1 + XG_BU) * V) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.g_lo + tile_cell0 * V), 0, (int)((((long)(XG_BT - 1) * U1 + XG_BU) * V) * 2), 0x00020000);
+    int lvo[4];  // byte offset of this lane's piece of line n in the buffer: row (t0 + 2 wave + (n >> 1), u0 + 8 (n & 1) + lrow)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int lt = 2 * wave + (n >> 1), lu = 8 * (n & 1) + lrow;
+        const bool ex = t0 + lt < T && u0 + lu < U1;
+        lvo[n] = ex ? (int)(((long)lt * U1 + lu) * V * 4) + 64 * (lpiece >> 2) + 16 * (lpiece & 3) : 0x7ffffff0;
+    }
+    // lo plane: the pair's 64 bytes per row (half a line: a whole line would need four k-steps of fragments in the exchange),
+    // lane L -> row 16n + (L >> 2) (n = 0, 1: two store instructions, 16 half lines each), piece L & 3 = (k-step parity, half)
+    const int xl2 = lds0 + 2 * XG_WSLOT + ((lane >> 1) & 1) * XG_XSLOT + wave * 3072 + 2 * 1024 + 16 * ((lane >> 2) + 32 * (lane & 1));
+    int lvo2[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int lt = 2 * wave + n, lu = lane >> 2;
+        const bool ex = t0 + lt < T && u0 + lu < U1;
+        lvo2[n] = ex ? (int)(((long)lt * U1 + lu) * V * 2) + 16 * (lane & 3) : 0x7ffffff0;
+    }
+    const int lovo = pexists ? (int)((((long)(prow >> 4)) * U1 + (prow & 15)) * V * 2) + 16 * half : 0x7ffffff0;  // (pipeline prologue / LINES_LO off)
 
     f32x16 acc[2][8];
 #pragma unroll
@@ -1044,7 +1444,6 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
 
-    const int lds0 = (int)(size_t)(lds_vptr)s_dh;
     const int xw = lds0 + 2 * XG_WSLOT + wave * 3072 + 16 * lane;       // exchange write: [slot][M tile wave][plane][lane]
     const int xa = lds0 + 2 * XG_WSLOT + (2 * wm) * 3072 + 16 * lane;   // exchange read: M tiles 2wm, 2wm+1
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                  // W read: tiles 8wn .. 8wn+7 of each plane
@@ -1107,7 +1506,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
             asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(dst), "v"(P.pl) : "memory");
         }
-        if (sl >= 9 && sl <= 11 && FIRST && pexists && !X3_OFF(2)) {  // the three stores, one slice each
+        if (LINES) {
+            // the lo plane's store (slice 11); the hi | mid planes leave as whole lines (line_read / line_store below)
+            if (sl == 11 && !X3_OFF(2) && !LINES_LO) __builtin_amdgcn_raw_buffer_store_b128(P.pl, lrs, lovo, 32 * c, 0);
+        } else if (sl >= 9 && sl <= 11 && FIRST && pexists && !X3_OFF(2)) {  // the three stores, one slice each
             if (X3_OFF(256)) {  // experiment: the same three stores, all to one cache-resident kilobyte (NOT a valid build)
                 u32x4 *dump = (u32x4 *)(a.g_lo + zrow * V) + lane;
                 if (sl == 9) dump[0] = P.ph; else if (sl == 10) dump[64] = P.pm; else dump[128] = P.pl;
@@ -1150,6 +1552,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             GXSTAMP(0);
             if (X3_OFF(512)) {}  // experiment: no wait at all (NOT a valid build: the W ring may be read before it landed)
             else if (X3_OFF(4) || X3_OFF(2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (LINES_LO && (j & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // behind the previous (even) k-step's DMAs: 4 + 2 line stores, 2 raw loads
+            else if (LINES_LO) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // previous k-step odd: 2 raw loads
+            else if (LINES && (j & 1)) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // lo store, 4 line stores, 2 raw loads
+            else if (LINES) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");            // previous k-step odd: lo store, 2 raw loads
             else if (FIRST && wave_stores) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // 3 G stores + 2 raw loads behind the DMAs
             else if (FIRST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // a wave without an existing cell issues no store
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -1180,6 +1586,24 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             const Raw &rawn = xr[(j + 1) & 3];
             // MEM: the k-step's five HBM operations, spread one per half block behind the DMAs (0: none; 1: G hi + mid
             // stores; 2: G lo store + first logits load; 3: second logits load)
+            u32x4 ln[4];  // the pair's lines, 16 bytes per lane each (even k-steps)
+            auto line_read = [&](u32x4 &v, auto n_c) {  // rows 8n .. 8n+7 of the M tile: lane slot + 8n
+                const int xl_ = xl;  // (a local: asm operands cannot name a capture of the enclosing generic lambda)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(xl_), "n"(128 * decltype(n_c)::value));
+            };
+            u32x4 ll[2];  // the pair's lo half lines
+            auto lo_read = [&](u32x4 &v, auto n_c) {  // rows 16n .. 16n+15 of the M tile
+                const int xl_ = xl2;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(xl_), "n"(256 * decltype(n_c)::value));
+            };
+            auto lo_store = [&](u32x4 &v, int n, int ce) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) :: "memory");
+                if (!X3_OFF(2)) __builtin_amdgcn_raw_buffer_store_b128(v, lrs, lvo2[n], 64 * (ce >> 1), 0);
+            };
+            auto line_store = [&](u32x4 &v, int n, int ce) {  // line n of the pair (ce, ce + 1): chunk ce >> 1 of the rows
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) :: "memory");
+                if (!X3_OFF(2)) __builtin_amdgcn_raw_buffer_store_b128(v, grs, lvo[n], 128 * (ce >> 1), 0);
+            };
             auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto s0_c, auto mem_c) {
                 constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value, S0 = decltype(s0_c)::value;
                 constexpr int MEM = decltype(mem_c)::value;
@@ -1193,11 +1617,29 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
                     if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
                     if (S0 >= 0 && S0 + q < 9 && prod_on && !(X3_OFF(32) && S0 + q < 8)) produce_slice(P, rawn, c + 1, (S0 < 0 ? 0 : S0) + q);
+                    if (LINES) {
+                        // even k-step c: G of k-steps c and c+1 is in the exchange -> the pair's lines; every k-step: lo store, 2 raw loads
+                        if (MEM == 1 && q == 1 && !(j & 1) && prod_on) { line_read(ln[0], X3Int<0>{}); line_read(ln[1], X3Int<1>{}); }
+                        if (MEM == 1 && q == 3 && !(j & 1) && prod_on) { line_read(ln[2], X3Int<2>{}); line_read(ln[3], X3Int<3>{}); }
+                        if (MEM == 1 && q == 5 && prod_on) {
+                            if (!LINES_LO) produce_slice(P, rawn, c + 1, 11);
+                            else if (!(j & 1)) { lo_read(ll[0], X3Int<0>{}); lo_read(ll[1], X3Int<1>{}); }
+                        }
+                        if (LINES_LO && MEM == 3 && q == 2 && !(j & 1) && prod_on) lo_store(ll[0], 0, c);
+                        if (LINES_LO && MEM == 3 && q == 4 && !(j & 1) && prod_on) lo_store(ll[1], 1, c);
+                        if (MEM == 2 && q == 1 && !(j & 1) && prod_on) line_store(ln[0], 0, c);
+                        if (MEM == 2 && q == 3 && !(j & 1) && prod_on) line_store(ln[1], 1, c);
+                        if (MEM == 2 && q == 5 && !(j & 1) && prod_on) line_store(ln[2], 2, c);
+                        if (MEM == 3 && q == 1 && !(j & 1) && prod_on) line_store(ln[3], 3, c);
+                        if (MEM == 3 && q == 3 && !X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5, 1);
+                        if (MEM == 3 && q == 5 && !X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5, 2);
+                    } else {
                     if (MEM == 1 && q == 1 && prod_on) produce_slice(P, rawn, c + 1, 9);
                     if (MEM == 1 && q == 5 && prod_on) produce_slice(P, rawn, c + 1, 10);
                     if (MEM == 2 && q == 1 && prod_on) produce_slice(P, rawn, c + 1, 11);
                     if (MEM == 2 && q == 5 && !X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5, 1);
                     if (MEM == 3 && q == 1 && !X3_OFF(4)) xload(xr[(j + 1) & 3], c + 5, 2);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };

@@ -113,6 +113,8 @@ VARIANT_FWD_LDS_RING = 128
 VARIANT_FWD_ONE_WG_PER_TILE = 256
 VARIANT_X3_FP32_FWD = 4096  # bf16x3 route: this stage on the fp32 route's kernel (isolation checks; not bit-identical)
 VARIANT_X3_FP32_DH = 8192
+VARIANT_X3_FWD_2WG = 16384  # bf16x3 forward as two 4-wave workgroups per CU (k_joint_fwd_x3d<4>; measured slower than the default)
+VARIANT_X3_FWD_8W = 65536   # ... as one 8-wave workgroup per CU (k_joint_fwd_x3d<8>)
 STAGES_ALL = 255
 STAGES_FORWARD = 7  # operand producers + joint-forward GEMM + lattice sweep: costs only
 
