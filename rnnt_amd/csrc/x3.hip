@@ -561,8 +561,13 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
     const int xa = lds0 + 2 * XF_WSLOT + (2 * wm) * 3072 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
     const int xw = lds0 + 2 * XF_WSLOT + wave * 3072 + 16 * lane;       // A write: M tile `wave` (this lane's own fragment slot)
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                 // W read: tiles 8wn .. 8wn+7 of each plane
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, npass * KC * 49152, 0x00020000);
-    const int wvo = lane * 16;
+    // (experiment 131072: W pieces by LDS-DMA with NO address register — the descriptor's ADD_TID_ENABLE (word 3 bit 23; stride
+    // 16 in word 1; the DATA_FORMAT bits extend the stride in this mode and stay 0) adds lane x 16 bytes itself.  Fetches the
+    // same bytes (tools/dma_vs_mfma.hip) and changes nothing: 33.2 vs 33.3 ms here, 32.3 vs 32.1 in k_dhidden_x3 — a DMA's
+    // issue cost is not its address register.)
+    const __amdgpu_buffer_rsrc_t wrs = !X3_OFF(131072) ? __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, npass * KC * 49152, 0x00020000)
+                                                       : __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 16, 0x7fffffff, 0x00800000);
+    const int wvo = !X3_OFF(131072) ? lane * 16 : 0;
 
     // Persistent workgroups (one per CU: 120 KiB of LDS), tiles from one atomic counter, the next tile requested a
     // tile ahead.
@@ -1449,8 +1454,9 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                  // W read: tiles 8wn .. 8wn+7 of each plane
     // W DMA: wave w copies pieces 12w .. 12w+11 of the k-step's 48 (piece = 1 KiB = one (plane, tile))
     // W k-steps by raw-buffer LDS-DMA: scalar base (this launch's 512-column pass) and offsets, one constant per-lane offset
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((char *)a.wpack_dh + (long)hp * VC * 49152, 0, VC * 49152, 0x00020000);
-    const int wvo = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs = !X3_OFF(131072) ? __builtin_amdgcn_make_buffer_rsrc((char *)a.wpack_dh + (long)hp * VC * 49152, 0, VC * 49152, 0x00020000)
+                                                       : __builtin_amdgcn_make_buffer_rsrc((char *)a.wpack_dh + (long)hp * VC * 49152, 16, 0x7fffffff, 0x00800000);
+    const int wvo = !X3_OFF(131072) ? lane * 16 : 0;  // (experiment 131072: TID-addressed, as in k_joint_fwd_x3)
 
     struct Raw { f32x4 x0, x1; u32x4 l; };  // FIRST: 8 fp32 logits; else: hi | mid (as x0, x1 bits) and lo planes
     auto xload = [&](Raw &r, int c, int part = 3) {  // part: 1 first half, 2 second half, 3 both (FIRST)
