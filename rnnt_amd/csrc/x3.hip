@@ -724,6 +724,10 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
             XSTAMP(0);
             if (X3_OFF(512)) {}  // experiment: no wait at all (NOT a valid build)
             else if (kc == 0 || X3_OFF(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (behind the k-step's last DMA (block 2) come only the first pass's 3 hidden stores; the 4 operand loads sit
+            // between the two DMA groups and retire with them)
+            else if (!X3_OFF(2097152) && STORE) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (!X3_OFF(2097152)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (STORE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             XSTAMP(1);
@@ -757,18 +761,23 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
                     }
                     if (NB >= 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
                     // D0: W DMA pieces D0+q of k-step cs+1; PB: production pieces PB+q of A's k-step cs+1
-                    if (D0 >= 0 && D0 + q < 12) wdma(csn, (D0 < 0 ? 0 : D0) + q);
+                    // W DMA pieces of k-step cs+1: six each in blocks 1 and 2, none beside block 0's eight fragment reads
+                    // (round 3 had 8 + 4 in blocks 0 and 1: 36.5 -> 35.9 ms on one box; experiment 2097152 = the old placement)
+                    if (!X3_OFF(2097152)) {
+                        if (D0 == 8 && q < 6) wdma(csn, q);
+                        if (D0 == -2 && q < 6) wdma(csn, 6 + q);
+                    } else if (D0 >= 0 && D0 + q < 12) wdma(csn, (D0 < 0 ? 0 : D0) + q);
                     if (PB >= 0 && PB + q < 17) prod_piece(P, ocur, (cs + 1) & 1, (PB < 0 ? 0 : PB) + q);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             // every fragment read is issued at least a block (16 MFMAs) before the wait that covers it
             XSTAMP(3);
-            block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<-1>{});    // ah.bh + reads of W mid, DMA 0-7
-            block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // am.bh + DMA 8-11
+            block(X3Int<0>{}, bf, bn, X3Int<1>{}, X3Int<0>{}, X3Int<-1>{});    // ah.bh + reads of W mid
+            block(X3Int<1>{}, bf, bn, X3Int<-1>{}, X3Int<8>{}, X3Int<-1>{});   // am.bh + DMA 0-5
             XSTAMP(4);
             op_load(onext, kcnn);  // operands of k-step cs+2: behind the DMAs (they are needed a whole k-step from now)
-            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<-1>{}, X3Int<0>{});   // al.bh + A(cs+1): tanh pieces
+            block(X3Int<2>{}, bf, bf, X3Int<-1>{}, X3Int<-2>{}, X3Int<0>{});   // al.bh + DMA 6-11 (D0 = -2: the tag of this block) + A(cs+1): tanh pieces
             XG_WAIT8(bn);
             block(X3Int<0>{}, bn, bf, X3Int<2>{}, X3Int<-1>{}, X3Int<8>{});    // ah.bm + reads of W lo (into the hi registers), A(cs+1): split pieces
             XSTAMP(5);
@@ -1621,7 +1630,15 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                     }
                     if (NB >= 0 && !X3_OFF(64))
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bnext[q]) : "v"(ws), "n"((NB < 0 ? 0 : NB) * 16384 + q * 1024));
-                    if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
+                    // the 12 W DMAs of k-step c+1 ride in blocks 1 and 2 (six each, one per MFMA pair), none beside block 0's eight
+                    // fragment reads and exp2 slices: 32.7 -> 32.3 ms against four per block in blocks 0-2 (a DMA's issue costs the
+                    // more the more LDS / VALU traffic its phase carries); a burst of 12 at one point: 36 ms
+                    if (X3_OFF(262144)) {
+                        if (D0 >= 0 && (q & 1) == 0 && D0 + q / 2 < 12) wdma(c + 1, (D0 < 0 ? 0 : D0) + q / 2);
+                    } else {
+                        if (D0 == 4 && q < 6) wdma(c + 1, q);
+                        if (D0 == 8 && q < 6) wdma(c + 1, 6 + q);
+                    }
                     if (S0 >= 0 && S0 + q < 9 && prod_on && !(X3_OFF(32) && S0 + q < 8)) produce_slice(P, rawn, c + 1, (S0 < 0 ? 0 : S0) + q);
                     if (LINES) {
                         // even k-step c: G of k-steps c and c+1 is in the exchange -> the pair's lines; every k-step: lo store, 2 raw loads
