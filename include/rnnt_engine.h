@@ -273,6 +273,30 @@ int rnnt_engine_conv_predictor_bwd(const int64_t *ids, int B, int U1, int S, int
                                    void *stream);
 
 /*
+ * Device-resident greedy decode of ONE utterance (next-step row SURVEY.md 8f-2, second half): the whole loop of
+ * rnnt/model.py:108-125 — scan frames from t for the first non-blank argmax, append the token, at most `max_per_frame`
+ * tokens per frame, re-run the predictor — with the stateless ConvPredictor of rnnt/predictor.py:189-229 (eval mode:
+ * no dropout) evaluated incrementally on the device (its output frame is a function of the last 7 tokens).  The call
+ * only ENQUEUES: (init != 0) state initialisation, then `iterations` times a fixed kernel sequence (0 = the upper bound
+ * max_length + ceil(T / scan_frames) + 1) whose kernels return at once after the loop has ended.  A caller may enqueue the
+ * bound in one call, or a chunk at a time (init = 1 first, then init = 0 with the same buffers) and stop when the loop is
+ * over: `host_flag` (NULL, or one int32 of PINNED host memory the caller zeroed) is set to 1 by the device when the loop
+ * ends and can be polled without a synchronisation.  The caller synchronises once and reads
+ *   state  int32[8]: [0] t, [1] emitted, [2] ntok = decoded tokens, [3] done, [5] iterations that did work;
+ *   tokens int32[max_length]: tokens[0] = blank (rnnt/model.py:100), tokens[1 .. ntok] = the decoded ids.
+ * frames [T,H] fp32 audio frames, rows frame_stride apart, unit element stride (already projected by audio_ln when the
+ * joint has one); text_W [H,O] / text_b [H]: joint.text_ln, or NULL when the joint adds the predictor output directly
+ * (then O == H); W [V,H], bias [V]: joint_ln.  E, O <= 1024, E % 4 == 0, O % 4 == 0, H % 8 == 0, V % 4 == 0,
+ * 1 <= scan_frames <= 128, max_length >= 2.
+ */
+int rnnt_engine_greedy_decode_workspace_bytes(int H, int V, int E, int O, int scan_frames, size_t *out);
+int rnnt_engine_greedy_decode(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p,
+                              int S, int E, int O, float ln_eps, const void *text_W, const void *text_b,
+                              const void *W, const void *bias, int H, int V, int blank, int max_length,
+                              int max_per_frame, int scan_frames, int iterations, int init, int32_t *host_flag,
+                              int32_t *state, int32_t *tokens, void *workspace, size_t ws_bytes, void *stream);
+
+/*
  * y = x W^T + b and its backward as MFMA kernels: the joint's optional input projections
  * audio_ln / text_ln (next-step row SURVEY.md 8f-1; reference rnnt/joint.py:8-12,26-30).
  * x [M,K] with rows ldx floats apart, W [N,K] (torch.nn.Linear layout), y / dy [M,N] contiguous.

@@ -10,6 +10,7 @@
 //   out[2 + k] = argmax of frame t0 + k                 (first index on ties, like torch.argmax)
 // so the host synchronises once per emitted token or per all-blank block.
 #include "kernels.hpp"
+#include "smallgemm.hpp"
 
 // logits[k, v] = tanh(enc[t0+k, :] + pred[:]) . W[v, :] + bias[v] for a handful of frames: M is tiny,
 // so the parallelism is over the vocabulary — one workgroup per 32 vocabulary rows (x 32 frames),
@@ -103,4 +104,314 @@ __global__ __launch_bounds__(1024) void k_argmax_scan(const float *__restrict__ 
 void launch_argmax_scan(const float *logits, int K, int V, int blank, int t0, int32_t *out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_argmax_scan, dim3(1), dim3(1024), 0, st, logits, K, V, blank, t0, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-resident greedy decode (round 4; SURVEY.md §8f rank 2, second half): the whole loop of reference
+// rnnt/model.py:108-125 for one utterance and the stateless ConvPredictor (rnnt/predictor.py:189-229) as a fixed
+// kernel sequence per ITERATION with every decision taken on the device — the host enqueues an upper bound of
+// iterations and synchronises ONCE per utterance (rnnt_engine_greedy_scan alone still needed one sync per token).
+//
+// state (int32[8]): [0] t  [1] emitted  [2] ntok (tokens after the leading blank)  [3] done  [4] newtok
+// tokens (int32[max_length]): tokens[0] = blank (model.py:100), tokens[1 .. ntok] the decoded ids.
+//
+// The reference re-runs the predictor on the whole history and keeps the LAST frame; the module is causal (left
+// zero padding, rnnt/causalconv.py:28-29), so that frame is a function of the last 7 tokens only, computed here
+// incrementally: rings of the last LayerNorm'd embeddings (conv1's input) and conv1 outputs (conv2's input),
+// zero-initialised = the left padding.  One row per step: the layers are matrix-VECTOR products (k_dec_gemv: a wave
+// per output feature over the [tap][out][in] pack of launch_pack_conv_w), LayerNorms are folded into their
+// consumers (every workgroup normalises its input vector itself: a few hundred floats).
+//
+// Iteration = [conv1 <- LN(embedding[token])] [conv2] [linear] [text_ln(LN(.)) if the joint has one] [scan logits of
+// `n` frames from t] [argmax + the loop's bookkeeping]; the predictor kernels return at once when the previous
+// iteration emitted nothing (an all-blank block), every kernel when the loop is over.
+// ---------------------------------------------------------------------------------------
+__global__ void k_dec_init(int32_t *state, int32_t *tokens, float *rings, int nring, int blank)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nring) rings[i] = 0.f;
+    if (i == 0) {
+        state[0] = 0; state[1] = 0; state[2] = 0; state[3] = 0; state[4] = 1; state[5] = 0; state[6] = 0; state[7] = 0;
+        tokens[0] = blank;
+    }
+}
+
+__device__ __forceinline__ float dec_block_sum(float v, float *red)  // 256 threads; red[4]
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float dec_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// y[o] = act(bias[o] + sum_tap sum_i Wp[(tap * N + o) * K + i] * x_tap[i]),  one wave per o, 4 per workgroup.
+// MODE 0: x_tap = ring[(p - (TAPS-1) + tap) & mask] (zeros for positions < 0), p = ntok: the ring's newest entry.
+// MODE 2: as 0, but the newest tap is LN(embedding[tokens[p]]) computed here (workgroup 0 also stores it in the ring).
+// MODE 1: TAPS = 1, x = LN(vec) (gamma, beta, eps): the LayerNorm of the producer folded in.
+// MODE 3: NO product: y = LN(vec) (N == K).
+// Output: out + (ring_out ? (p & out_mask) * N : 0).  K % 4 == 0, K <= 1024.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dec_gemv(const int32_t *__restrict__ state, const int32_t *__restrict__ tokens,
+                                                   const float *__restrict__ Wp, const float *__restrict__ bias,
+                                                   const float *__restrict__ in, int in_mask, int taps, int K, int N, int act,
+                                                   const float *__restrict__ emb_or_gamma, const float *__restrict__ gamma_or_beta,
+                                                   const float *__restrict__ beta, float eps, int S,
+                                                   float *__restrict__ out, int ring_out, int out_mask, float *__restrict__ ring_store)
+{
+    __shared__ float xs[5 * 1024];
+    __shared__ float red[4];
+    if (state[3] || !state[4]) return;  // the loop is over / nothing new to predict from (workgroup-uniform)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = state[2];
+    // this wave's weights (one output feature: taps x K floats, <= 20 float4 per lane) are requested FIRST: their round
+    // trip through L2 overlaps the staging / normalisation of the input vector (a chain of dependent loads, reductions and
+    // barriers: 6.3 us per layer with the weights behind it, tools/bench_decode.py)
+    const int o = blockIdx.x * 4 + wave, oc = o < N ? o : N - 1;
+    f32x4 wreg[5][4];
+    if (MODE != 3) {
+#pragma unroll
+        for (int tap = 0; tap < 5; ++tap)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * lane + 256 * j;
+                wreg[tap][j] = (tap < taps && i < K) ? *(const f32x4 *)(Wp + ((long)tap * N + oc) * K + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    if (MODE == 1 || MODE == 3) {  // x = LN(in) * gamma + beta
+        float s = 0.f, s2 = 0.f;
+        for (int i = tid; i < K; i += 256) { const float v = in[i]; s += v; }
+        const float mean = dec_block_sum(s, red) / K;
+        for (int i = tid; i < K; i += 256) { const float d = in[i] - mean; s2 += d * d; }
+        const float rstd = rsqrtf(dec_block_sum(s2, red) / K + eps);
+        for (int i = tid; i < K; i += 256) {
+            const float y = (in[i] - mean) * rstd * emb_or_gamma[i] + gamma_or_beta[i];
+            if (MODE == 3) { if (blockIdx.x == 0) out[i] = y; }
+            else xs[i] = y;
+        }
+        if (MODE == 3) return;
+    } else {
+        for (int tap = 0; tap < taps; ++tap) {
+            const int q = p - (taps - 1) + tap;
+            if (MODE == 2 && tap == taps - 1) continue;
+            const float *src = in + (long)(q & in_mask) * K;
+            for (int i = tid; i < K; i += 256) xs[tap * K + i] = q >= 0 ? src[i] : 0.f;
+        }
+        if (MODE == 2) {  // newest tap: LN(embedding[token])  (rnnt/predictor.py:214-215)
+            int tok = tokens[p];
+            tok = tok < 0 ? 0 : (tok >= S ? S - 1 : tok);
+            const float *e = emb_or_gamma + (long)tok * K;
+            float s = 0.f, s2 = 0.f;
+            for (int i = tid; i < K; i += 256) s += e[i];
+            const float mean = dec_block_sum(s, red) / K;
+            for (int i = tid; i < K; i += 256) { const float d = e[i] - mean; s2 += d * d; }
+            const float rstd = rsqrtf(dec_block_sum(s2, red) / K + eps);
+            for (int i = tid; i < K; i += 256) {
+                const float y = (e[i] - mean) * rstd * gamma_or_beta[i] + beta[i];
+                xs[(taps - 1) * K + i] = y;
+                if (blockIdx.x == 0) ring_store[(long)(p & in_mask) * K + i] = y;
+            }
+        }
+    }
+    __syncthreads();
+    if (o >= N) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 5; ++tap)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * lane + 256 * j;
+            if (tap < taps && i < K) {
+                const f32x4 wv = wreg[tap][j], xv = *(const f32x4 *)(xs + tap * K + i);
+                acc = fmaf(wv[0], xv[0], acc); acc = fmaf(wv[1], xv[1], acc); acc = fmaf(wv[2], xv[2], acc); acc = fmaf(wv[3], xv[3], acc);
+            }
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[o] : 0.f);
+        if (act) v = dec_gelu(v);
+        out[(ring_out ? (long)(p & out_mask) * N : 0) + o] = v;
+    }
+}
+
+// the scan of `K` frames from t = state[0] (frames past T-1 repeat the last one; k_dec_update ignores them): each
+// workgroup's 32 frames x 32 vocabulary entries leave as ONE (max, first index) pair per frame — part[frame][v block] —
+// not as logits: k_dec_update then looks at V/32 candidates per frame instead of V values
+// LN: `pred` is the predictor's un-normalised output z (no text_ln in the joint): every workgroup applies the output
+// LayerNorm itself (H <= 1024 floats; saves the iteration a kernel), keeping the result in LDS.
+template <bool LN>
+__global__ __launch_bounds__(256) void k_dec_scan_logits(const int32_t *__restrict__ state, const float *__restrict__ enc, long enc_st, int T,
+                                                         const float *__restrict__ pred, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float2 *__restrict__ part, int K, int H, int V,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta, float eps)
+{
+    __shared__ float s_acc[3][16][64];
+    __shared__ __attribute__((aligned(16))) float s_pred[LN ? 1024 : 4];
+    __shared__ float red[4];
+    if (state[3]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int v0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int t0 = state[0];
+    const int frame = min(t0 + min(k0 + i, K - 1), T - 1), vrow = min(v0 + i, V - 1);
+    const float *er = enc + (long)frame * enc_st + 4 * half;
+    if (LN) {  // y = LN(z) * gamma + beta   (rnnt/predictor.py:229)
+        const int tid = threadIdx.x;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = tid; j < H; j += 256) s1 += pred[j];
+        const float mean = dec_block_sum(s1, red) / H;
+        for (int j = tid; j < H; j += 256) { const float d = pred[j] - mean; s2 += d * d; }
+        const float rstd = rsqrtf(dec_block_sum(s2, red) / H + eps);
+        for (int j = tid; j < H; j += 256) s_pred[j] = (pred[j] - mean) * rstd * gamma[j] + beta[j];
+        __syncthreads();
+    }
+    const float *pr = (LN ? (const float *)s_pred : pred) + 4 * half;
+    const float *wr = W + (long)vrow * H + 4 * half;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A chunk (8 h: 4 MFMAs, ~256 matrix-pipe cycles) does not cover an L2 round trip and a 32-frame block is only V/32
+    // workgroups: the wave's chunks go in GROUPS of 8 with all 24 loads of the next group in flight while the current
+    // one is multiplied (two chunks ahead measured 21 us per block at H = 1024: one round trip per chunk).
+    const int NC = H / 8;
+    struct Ops { f32x4 e, p, w; };
+    auto load = [&](Ops &o, int c) {
+        const int cc = c < NC ? c : NC - 1;
+        o.e = *(const f32x4 *)(er + 8 * cc); o.p = *(const f32x4 *)(pr + 8 * cc); o.w = *(const f32x4 *)(wr + 8 * cc);
+    };
+    auto load8 = [&](Ops (&g)[8], int c0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load(g[j], c0 + 4 * j);
+    };
+    auto mul8 = [&](const Ops (&g)[8], int c0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + 4 * j < NC) {  // wave-uniform
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fast_tanh(g[j].e[s] + g[j].p[s]), g[j].w[s], acc, 0, 0, 0);
+            }
+    };
+    Ops ga[8], gb[8];
+    load8(ga, wave);
+    for (int c = wave; c < NC; c += 64) {  // two groups (2 x 8 chunks x 4 waves) per trip
+        load8(gb, c + 32);
+        mul8(ga, c);
+        load8(ga, c + 64);
+        mul8(gb, c + 32);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int v = v0 + i;
+        const float bv = v < V ? bias[v] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float x = ((acc[r] + s_acc[0][r][lane]) + (s_acc[1][r][lane] + s_acc[2][r][lane])) + bv;
+            if (v >= V) x = RNNT_NEG_INF;
+            const float M = half_max_dpp(x, half);  // every lane of the half: the maximum of the frame's 32 entries
+            const unsigned long long hit = __ballot(x == M);  // first lane of the half that holds it = the lowest index
+            const unsigned h32 = half ? (unsigned)(hit >> 32) : (unsigned)hit;
+            if (i == 0 && k < K) part[(long)k * gridDim.x + blockIdx.x] = float2{M, __int_as_float(v0 + __builtin_ctz(h32))};
+        }
+    }
+}
+
+// argmax of every scanned frame from its V/32 candidates (first index on ties, like torch.argmax: candidates are in
+// increasing index order), then the loop's bookkeeping (rnnt/model.py:108-125; the host-side twin: rnnt_amd/model.py):
+//   hit = first frame of [t, t + n) whose argmax is not blank, n = min(K, T - t)
+//   none: t += n, emitted = 0                                  (an all-blank block)
+//   else: t = hit (emitted = 0 if hit > t), append the token, ++emitted; emitted == max_per_frame: ++t, emitted = 0
+//   done = t >= T or 1 + ntok >= max_length
+__global__ __launch_bounds__(128) void k_dec_update(const float2 *__restrict__ part, int K, int NB, int blank, int T, int max_length,
+                                                    int max_per_frame, int32_t *__restrict__ state, int32_t *__restrict__ tokens,
+                                                    int32_t *host_flag)
+{
+    __shared__ int s_tok[128];
+    if (state[3]) return;
+    if ((int)threadIdx.x < K) {
+        const float2 *p = part + (long)threadIdx.x * NB;
+        float best = RNNT_NEG_INF;
+        int bi = 0;
+        for (int j = 0; j < NB; ++j) {
+            const float2 c = p[j];
+            if (c.x > best) { best = c.x; bi = __float_as_int(c.y); }
+        }
+        s_tok[threadIdx.x] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = state[0], emitted = state[1], ntok = state[2];
+        const int n = min(K, T - t);
+        int hit = -1;
+        for (int k = 0; k < n; ++k)
+            if (s_tok[k] != blank) { hit = k; break; }
+        int newtok = 0;
+        if (hit < 0) { t += n; emitted = 0; }
+        else {
+            if (hit > 0) emitted = 0;
+            t += hit;
+            tokens[++ntok] = s_tok[hit];
+            newtok = 1;
+            if (++emitted >= max_per_frame) { ++t; emitted = 0; }
+        }
+        state[0] = t; state[1] = emitted; state[2] = ntok; state[4] = newtok;
+        const int done = (t >= T || ntok + 1 >= max_length) ? 1 : 0;
+        state[3] = done;
+        state[5] += 1;  // iterations that did work (diagnostic)
+        // the host's cue to stop enqueueing iterations (mapped pinned memory, polled without a synchronisation)
+        if (done && host_flag) __hip_atomic_store(host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+size_t dec_loop_workspace_floats(int H, int V, int E, int O, int nframes)
+{
+    // x1 ring [4][E], g1 ring [8][E], g2 [E], z [O], y [O], pvec [H], candidates [nframes][V/32] x 2, conv packs [3+5][E][E]
+    return (size_t)4 * E + 8 * E + E + 2 * (size_t)O + H + (size_t)nframes * ((V + 31) / 32) * 2 + (size_t)8 * E * E + 64;
+}
+
+void launch_dec_loop(const DecLoopArgs &a, hipStream_t st)
+{
+    float *ws = (float *)a.workspace;
+    const int E = a.E, O = a.O, H = a.H, V = a.V, n = a.scan_frames;
+    float *x1ring = ws, *g1ring = x1ring + 4 * (size_t)E, *g2 = g1ring + 8 * (size_t)E, *z = g2 + E, *y = z + O, *pvec = y + O;
+    const int NB = (V + 31) / 32;
+    float2 *part = (float2 *)(pvec + ((H + 15) / 16) * 16);
+    float *wp1 = (float *)(part + (size_t)n * NB), *wp2 = wp1 + (size_t)3 * E * E;
+    const int nring = 12 * E;
+    if (a.init) {
+        hipLaunchKernelGGL(k_dec_init, dim3((nring + 255) / 256), dim3(256), 0, st, a.state, a.tokens, x1ring, nring, a.blank);
+        launch_pack_conv_w(a.p.conv1_w, wp1, E, E, 3, st);  // [tap][out][in]
+        launch_pack_conv_w(a.p.conv2_w, wp2, E, E, 5, st);
+    }
+    const float *nul = nullptr;
+    for (int it = 0; it < a.iterations; ++it) {
+        // g1[p] = gelu(conv1(LN(embedding[token p]), x1[p-1], x1[p-2]))            predictor.py:214-219 (dropout: eval)
+        hipLaunchKernelGGL(k_dec_gemv<2>, dim3((E + 3) / 4), dim3(256), 0, st, a.state, a.tokens, wp1, a.p.conv1_b, x1ring, 3, 3, E, E, 1,
+                           a.p.embedding, a.p.ln_in_w, a.p.ln_in_b, a.ln_eps, a.S, g1ring, 1, 7, x1ring);
+        // g2 = gelu(conv2(g1[p-4 .. p]))                                            predictor.py:222-223
+        hipLaunchKernelGGL(k_dec_gemv<0>, dim3((E + 3) / 4), dim3(256), 0, st, a.state, a.tokens, wp2, a.p.conv2_b, g1ring, 7, 5, E, E, 1,
+                           nul, nul, nul, 0.f, 0, g2, 0, 0, (float *)nullptr);
+        // z = linear(g2)                                                            predictor.py:228
+        hipLaunchKernelGGL(k_dec_gemv<0>, dim3((O + 3) / 4), dim3(256), 0, st, a.state, a.tokens, a.p.linear_w, a.p.linear_b, g2, 0, 1, E, O, 0,
+                           nul, nul, nul, 0.f, 0, z, 0, 0, (float *)nullptr);
+        // the joint's text input: text_ln(LN(z)) (rnnt/joint.py:28-30), or LN(z) itself — then applied by the scan's workgroups
+        if (a.text_W) {
+            hipLaunchKernelGGL(k_dec_gemv<1>, dim3((H + 3) / 4), dim3(256), 0, st, a.state, a.tokens, a.text_W, a.text_b, z, 0, 1, O, H, 0,
+                               a.p.ln_out_w, a.p.ln_out_b, nul, a.ln_eps, 0, pvec, 0, 0, (float *)nullptr);
+            hipLaunchKernelGGL(k_dec_scan_logits<false>, dim3(NB, (n + 31) / 32), dim3(256), 0, st, a.state, a.frames, a.frame_stride, a.T,
+                               pvec, a.W, a.bias, part, n, H, V, nul, nul, 0.f);
+        } else {
+            hipLaunchKernelGGL(k_dec_scan_logits<true>, dim3(NB, (n + 31) / 32), dim3(256), 0, st, a.state, a.frames, a.frame_stride, a.T,
+                               z, a.W, a.bias, part, n, H, V, a.p.ln_out_w, a.p.ln_out_b, a.ln_eps);
+        }
+        hipLaunchKernelGGL(k_dec_update, dim3(1), dim3(128), 0, st, part, n, NB, a.blank, a.T, a.max_length, a.max_per_frame, a.state, a.tokens, a.host_flag);
+    }
 }

@@ -629,6 +629,62 @@ int rnnt_engine_greedy_scan(const void *enc, int64_t enc_stride_t, int64_t enc_s
     return launch_status("rnnt_engine_greedy_scan");
 }
 
+int rnnt_engine_greedy_decode_workspace_bytes(int H, int V, int E, int O, int scan_frames, size_t *out)
+{
+    if (!out) return fail(RNNT_ERR_INVALID_ARG, "null size pointer");
+    if (scan_frames < 1 || scan_frames > 128) return fail(RNNT_ERR_INVALID_ARG, "scan_frames=%d outside [1,128]", scan_frames);
+    if (int rc = check_dims(1, scan_frames, 1, H, V, RNNT_DTYPE_F32, true)) return rc;
+    if (H % 8 != 0) return fail(RNNT_ERR_UNSUPPORTED, "greedy decode needs H %% 8 == 0 (H=%d)", H);
+    if (E < 4 || O < 4 || E > 1024 || O > 1024 || E % 4 || O % 4)
+        return fail(RNNT_ERR_UNSUPPORTED, "greedy decode needs 4 <= E, O <= 1024, multiples of 4 (E=%d, O=%d)", E, O);
+    *out = align_up(dec_loop_workspace_floats(H, V, E, O, scan_frames) * 4);
+    return RNNT_OK;
+}
+
+int rnnt_engine_greedy_decode(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p,
+                              int S, int E, int O, float ln_eps, const void *text_W, const void *text_b,
+                              const void *W, const void *bias, int H, int V, int blank, int max_length,
+                              int max_per_frame, int scan_frames, int iterations, int init, int32_t *host_flag,
+                              int32_t *state, int32_t *tokens, void *workspace, size_t ws_bytes, void *stream)
+{
+    size_t need;
+    if (int rc = rnnt_engine_greedy_decode_workspace_bytes(H, V, E, O, scan_frames, &need)) return rc;
+    int32_t *flag_dev = nullptr;
+    if (host_flag) {  // the device's address of the caller's pinned word (an ordinary host pointer is refused, never written through)
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, host_flag, 0) != hipSuccess || !dp) {
+            (void)hipGetLastError();
+            return fail(RNNT_ERR_INVALID_ARG, "host_flag is not mapped pinned host memory (hipHostMalloc / torch pin_memory)");
+        }
+        flag_dev = (int32_t *)dp;
+    }
+    if (!frames || !p || !W || !bias || !state || !tokens || !workspace) return fail(RNNT_ERR_INVALID_ARG, "null pointer argument");
+    const void *ptrs[] = {p->embedding, p->ln_in_w, p->ln_in_b, p->conv1_w, p->conv1_b, p->conv2_w, p->conv2_b,
+                          p->linear_w, p->linear_b, p->ln_out_w, p->ln_out_b, W, bias, frames};
+    for (const void *q : ptrs)
+        if (!q || !aligned16(q)) return fail(RNNT_ERR_INVALID_ARG, "null or not 16-byte aligned parameter pointer");
+    if ((text_W == nullptr) != (text_b == nullptr) || (text_W && (!aligned16(text_W) || !aligned16(text_b))))
+        return fail(RNNT_ERR_INVALID_ARG, "text_W / text_b: both or neither, 16-byte aligned");
+    if (!text_W && O != H) return fail(RNNT_ERR_INVALID_ARG, "without text_ln the predictor's output dim (%d) must equal H (%d)", O, H);
+    if (T < 1 || S < 1 || max_length < 2 || max_per_frame < 1 || iterations < 0 || frame_stride < H || frame_stride % 4)
+        return fail(RNNT_ERR_INVALID_ARG, "T=%d S=%d max_length=%d max_per_frame=%d iterations=%d frame_stride=%lld", T, S, max_length,
+                    max_per_frame, iterations, (long long)frame_stride);
+    if (blank < 0 || blank >= V) return fail(RNNT_ERR_INVALID_ARG, "blank=%d outside [0,%d)", blank, V);
+    if ((uintptr_t)workspace & 255) return fail(RNNT_ERR_INVALID_ARG, "workspace must be 256-byte aligned");
+    if (ws_bytes < need) return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, need);
+    DecLoopArgs a;
+    a.frames = (const float *)frames; a.frame_stride = (long)frame_stride; a.T = T;
+    a.p = *p; a.S = S; a.E = E; a.O = O; a.ln_eps = ln_eps;
+    a.text_W = (const float *)text_W; a.text_b = (const float *)text_b;
+    a.W = (const float *)W; a.bias = (const float *)bias; a.H = H; a.V = V; a.blank = blank;
+    a.max_length = max_length; a.max_per_frame = max_per_frame; a.scan_frames = scan_frames;
+    a.iterations = iterations ? iterations : max_length + (T + scan_frames - 1) / scan_frames + 1;
+    a.init = init; a.host_flag = flag_dev;
+    a.state = state; a.tokens = tokens; a.workspace = workspace;
+    launch_dec_loop(a, (hipStream_t)stream);
+    return launch_status("rnnt_engine_greedy_decode");
+}
+
 int rnnt_engine_loss_fwd_bwd(const void *logits, const int32_t *targets, const int32_t *logit_lens,
                              const int32_t *target_lens, int B, int T, int U1, int V, int blank,
                              float clamp, int dtype, float *costs, void *grad_logits,

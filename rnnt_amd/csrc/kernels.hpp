@@ -1,6 +1,7 @@
 // kernels.hpp — host-side launcher declarations shared by the engine's translation units.
 #pragma once
 #include "common.hpp"
+#include "../../include/rnnt_engine.h"  // rnnt_conv_predictor_params (DecLoopArgs)
 
 // ---- engine.hip: sets the thread-local error message, returns `code`
 int engine_fail(int code, const char *fmt, ...);
@@ -167,3 +168,18 @@ void launch_dw_x3(const X3Args &a, hipStream_t st);
 void launch_scan_logits(const float *enc, long enc_st, const float *pred, const float *W, const float *bias,
                         float *logits, int K, int H, int V, hipStream_t st);
 void launch_argmax_scan(const float *logits, int K, int V, int blank, int t0, int32_t *out, hipStream_t st);
+
+// device-resident greedy decode (decode.hip)
+struct DecLoopArgs {
+    const float *frames; long frame_stride; int T;  // [T,H] audio frames (after audio_ln), h-stride 1
+    rnnt_conv_predictor_params p; int S, E, O; float ln_eps;
+    const float *text_W, *text_b;                   // joint.text_ln [H,O], [H] or NULL (then O == H)
+    const float *W, *bias; int H, V, blank;         // joint_ln
+    int max_length, max_per_frame, scan_frames, iterations;
+    int init;              // 1: initialise state, rings and weight packs first; 0: continue a decode in progress
+    int32_t *host_flag;    // device pointer of a mapped host word set to 1 when the loop ends, or NULL
+    int32_t *state, *tokens;
+    void *workspace;
+};
+size_t dec_loop_workspace_floats(int H, int V, int E, int O, int nframes);
+void launch_dec_loop(const DecLoopArgs &a, hipStream_t st);

@@ -1684,6 +1684,19 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             GXSTAMP(6);
         }
     }
+    // the epilogue's pred rows are requested BEFORE the drain below (they ride out the G stores' acknowledgements with it)
+    const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
+    const bool colok[2] = {colg[0] < H, colg[1] < H};
+    f32x4 pr[8][2];  // pred rows of this lane's 8 u slots, its 2 x 4 columns (zero where u >= U1 or the column >= H)
+    if (!X3_OFF(16)) {
+#pragma unroll
+        for (int r7 = 0; r7 < 8; ++r7) {
+            const int u = u0 + 8 * (r7 >> 2) + (r7 & 3) + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                pr[r7][g] = (u < U1 && colok[g]) ? *(const f32x4 *)(a.pred + ((long)b * U1 + u) * H + colg[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued ring loads / DMAs
     __syncthreads();
 
@@ -1699,34 +1712,33 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     }
     float (*s_red)[64][65] = (float (*)[64][65])s_dh;  // [wn][lane][8 u slots x 8 columns]
     const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
-    const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
-    const bool colok[2] = {colg[0] < H, colg[1] < H};
-    // hidden is RECOMPUTED from enc and pred (two small, cache-resident operands; the same fast_tanh_sum4 as the
-    // forward's prologue, so bit for bit the value whose planes the GEMMs multiplied) instead of re-reading its
-    // three planes: 6 bytes per element of HBM traffic in a kernel that already moves 68 GB in ~25 ms.
+    // The tanh' factor 1 - hidden^2 is RECOMPUTED from enc and pred (two small, cache-resident operands) instead of re-reading
+    // hidden's three planes (6 bytes per element of HBM traffic), in the form 1 - tanh^2(x) = 4 w / (1 + w)^2, w = exp(-2|x|):
+    // one exp2, one reciprocal and three multiplies per element on register PAIRS (v_pk_*; no MFMA runs beside this phase),
+    // no cancellation near |hidden| = 1, no overflow (w <= 1).  The factor 4 is applied to the sums (exact).
     // Rows outside the lattice have G = 0 and therefore an exactly zero accumulator: any finite value will do.
-    float psum[8][8];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto dfac_q = [](f2 x) {  // (1 - tanh^2 x) / 4 of two values
+        const f2 a = x * (2.0f * RNNT_LOG2E);
+        const f2 w = {__builtin_amdgcn_exp2f(-__builtin_fabsf(a[0])), __builtin_amdgcn_exp2f(-__builtin_fabsf(a[1]))};
+        const f2 e1 = w + 1.0f;
+        const f2 r = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+        return (w * r) * r;
+    };
+    f2 psum2[8][4];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) psum[k][q] = 0.f;
-    f32x4 pr[8][2];  // pred rows of this lane's 8 u slots, its 2 x 4 columns (zero where u >= U1 or the column >= H)
-#pragma unroll
-    for (int r7 = 0; r7 < 8; ++r7) {
-        const int u = u0 + 8 * (r7 >> 2) + (r7 & 3) + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-            pr[r7][g] = (u < U1 && colok[g]) ? *(const f32x4 *)(a.pred + ((long)b * U1 + u) * H + colg[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int q = 0; q < 4; ++q) psum2[k][q] = f2{0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
             const int tl = 2 * (2 * wm + mt) + rh;  // t row inside the tile
             const int t = t0 + tl;
-            float esum[8];
+            f2 esum2[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) esum[q] = 0.f;
+            for (int q = 0; q < 4; ++q) esum2[q] = f2{0.f, 0.f};
             f32x4 er[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -1734,15 +1746,18 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
 #pragma unroll
             for (int r7 = 0; r7 < 8; ++r7)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const f32x4 hv = fast_tanh_sum4(er[g], pr[r7][g]);
+                for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float d = acc[mt][g * 4 + q][rh * 8 + r7] * (1.f - hv[q] * hv[q]);
-                        esum[g * 4 + q] += d;
-                        psum[r7][g * 4 + q] += d;
+                    for (int qq = 0; qq < 2; ++qq) {  // columns 2qq, 2qq+1 of the group
+                        const f2 x = {er[g][2 * qq] + pr[r7][g][2 * qq], er[g][2 * qq + 1] + pr[r7][g][2 * qq + 1]};
+                        const f2 av = {acc[mt][g * 4 + 2 * qq][rh * 8 + r7], acc[mt][g * 4 + 2 * qq + 1][rh * 8 + r7]};
+                        const f2 d = av * dfac_q(x);
+                        esum2[g * 2 + qq] += d;
+                        psum2[r7][g * 2 + qq] += d;
                     }
-                }
+            float esum[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] = 4.0f * esum2[q >> 1][q & 1];
 #pragma unroll
             for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
             if (half == 0 && t < Tb) {
@@ -1754,6 +1769,11 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
                     }
             }
         }
+    float psum[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) psum[k][q] = 4.0f * psum2[k][q >> 1][q & 1];
     if (wm == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)

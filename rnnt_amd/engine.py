@@ -62,6 +62,8 @@ SIGNATURES = {
     "rnnt_engine_joint_bwd": "pppppiiiiiipppppzp",
     "rnnt_engine_greedy_scan_workspace_bytes": "iiip",
     "rnnt_engine_greedy_scan": "pqqpppiiiiippzp",
+    "rnnt_engine_greedy_decode_workspace_bytes": "iiiiip",
+    "rnnt_engine_greedy_decode": "pqipiiifppppiiiiiiiippppzp",
     "rnnt_engine_grad_norm_workspace_bytes": "ipp",
     "rnnt_engine_grad_norm": "ippppzp",
     "rnnt_engine_adamw_step": "ipppppdddddqpfip",
@@ -97,6 +99,7 @@ EXPORTS = (
     "rnnt_engine_joint_fwd", "rnnt_engine_loss_fwd_bwd", "rnnt_engine_joint_loss_fwd_bwd",
     "rnnt_engine_workspace_layout", "rnnt_engine_run_stage",
     "rnnt_engine_greedy_scan_workspace_bytes", "rnnt_engine_greedy_scan",
+    "rnnt_engine_greedy_decode_workspace_bytes", "rnnt_engine_greedy_decode",
     "rnnt_engine_joint_loss_fwd", "rnnt_engine_run_stages",
     "rnnt_engine_joint_bwd_workspace_bytes", "rnnt_engine_joint_bwd",
     "rnnt_engine_grad_norm_workspace_bytes", "rnnt_engine_grad_norm", "rnnt_engine_adamw_step",
@@ -501,3 +504,56 @@ def greedy_scan(enc, pred, W, bias, t0, nframes, blank):
                                              int(t0), nframes, H, V, int(blank), _p(out), _p(ws),
                                              ctypes.c_size_t(ws.numel()), _stream(dev)))
     return out
+
+
+class _PredParams(ctypes.Structure):  # include/rnnt_engine.h: rnnt_conv_predictor_params
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "embedding", "ln_in_w", "ln_in_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b", "linear_w",
+        "linear_b", "ln_out_w", "ln_out_b")]
+
+
+def greedy_decode_loop(frames, pred_params, ln_eps, text_W, text_b, W, bias, blank, max_length,
+                       max_per_frame=10, scan_frames=64, chunk=8):
+    """Device-resident greedy decode of one utterance (C ABI rnnt_engine_greedy_decode; reference
+    rnnt/model.py:108-125 with the stateless ConvPredictor).  `frames` [T,H] fp32 audio frames (after audio_ln),
+    `pred_params` the 11 ConvPredictor parameter tensors in rnnt_conv_predictor_params order, `text_W` / `text_b`
+    joint.text_ln's parameters or None.  Iterations are enqueued `chunk` at a time until the device has raised the
+    end-of-loop flag in a pinned host word (polled, never waited for) or the loop's upper bound is reached.
+    Returns (state int32[8], tokens int32[max_length]) device tensors WITHOUT synchronising: after one
+    synchronisation tokens[1 : 1 + state[2]] are the decoded ids."""
+    params = [t.contiguous() for t in pred_params]
+    dev = _require_cuda(frames, W, bias, *params)
+    _require_dtype(torch.float32, frames=frames, W=W, bias=bias, **{f"param{i}": t for i, t in enumerate(params)})
+    if frames.dim() != 2 or frames.stride(1) != 1:
+        frames = frames.contiguous()
+    T, H = frames.shape
+    V = W.shape[0]
+    S, E = params[0].shape
+    O = params[7].shape[0]
+    W, bias = W.contiguous(), bias.contiguous()
+    if text_W is not None:
+        _require_cuda(text_W, text_b)
+        _require_dtype(torch.float32, text_W=text_W, text_b=text_b)
+        text_W, text_b = text_W.contiguous(), text_b.contiguous()
+    scan_frames, chunk = int(scan_frames), max(1, int(chunk))
+    bound = int(max_length) + (T + scan_frames - 1) // scan_frames + 1
+    with torch.cuda.device(dev):
+        n = ctypes.c_size_t(0)
+        _check(lib().rnnt_engine_greedy_decode_workspace_bytes(H, V, E, O, scan_frames, ctypes.byref(n)))
+        ws = workspace(dev, n.value)
+        state = torch.empty(8, dtype=torch.int32, device=dev)
+        tokens = torch.empty(int(max_length), dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        st = _PredParams(*[t.data_ptr() for t in params])
+        stream = _stream(dev)
+        done = 0
+        while done < bound and (done == 0 or int(flag[0]) == 0):
+            it = min(chunk, bound - done)
+            _check(lib().rnnt_engine_greedy_decode(
+                _p(frames), ctypes.c_int64(frames.stride(0)), T, ctypes.byref(st), S, E, O, ctypes.c_float(ln_eps),
+                _p(text_W), _p(text_b), _p(W), _p(bias), H, V, int(blank), int(max_length), int(max_per_frame),
+                scan_frames, it, 1 if done == 0 else 0, ctypes.c_void_p(flag.data_ptr()), _p(state), _p(tokens), _p(ws),
+                ctypes.c_size_t(ws.numel()), stream))
+            done += it
+        state._keepalive = (flag, frames, params, W, bias, text_W, text_b)  # until the caller has synchronised
+    return state, tokens

@@ -43,12 +43,31 @@ class RNNTModel(torch.nn.Module):
 
     # ---- greedy decode (reference model.py:45-139); host loop, not on the engine's path
     def _predictor_is_stateful(self) -> bool:
-        params = inspect.signature(self.predictor.forward).parameters
-        return len(params) >= 2
+        # forward(ids, lengths[, state]) (the reference's LSTMPredictor) against forward(ids) (its ConvPredictor); optional
+        # extras with defaults — rnnt_amd.ConvPredictor's keep_masks test aid — do not make a predictor stateful
+        params = inspect.signature(self.predictor.forward).parameters.values()
+        required = [q for q in params if q.default is inspect.Parameter.empty
+                    and q.kind in (inspect.Parameter.POSITIONAL_ONLY, inspect.Parameter.POSITIONAL_OR_KEYWORD)]
+        return len(required) >= 2
+
+    def _device_loop_ok(self, audio) -> bool:
+        """The whole decode loop can run on the device (rnnt_engine_greedy_decode): stateless engine ConvPredictor in
+        eval mode, fp32 HIP tensors, sizes the decode kernels cover."""
+        from .predictor import ConvPredictor
+        p = self.predictor
+        if not (isinstance(p, ConvPredictor) and audio.is_cuda and audio.dtype == torch.float32):
+            return False
+        if p.training and float(p.dropout.p) > 0.0:
+            return False
+        E, O = p.embedding.embedding_dim, p.linear.out_features
+        H, V = self.joint.joint_ln.in_features, self.joint.joint_ln.out_features
+        if E % 4 or O % 4 or E > 1024 or O > 1024 or H % 8 or V % 4:
+            return False
+        return hasattr(self.joint, "text_ln") or O == H
 
     @torch.no_grad()
     def greedy_decode(self, mel_features: torch.Tensor, mel_feature_lens: torch.Tensor,
-                      max_length: int = 200, scan_frames: int = 32):
+                      max_length: int = 200, scan_frames: int = 32, device_loop=None):
         """Greedy decode with the reference's control flow (rnnt/model.py:95-125): emit the argmax
         token until blank or 10 symbols per frame, then advance.  The joint + argmax of up to
         `scan_frames` consecutive frames run on the engine per call (JointNetwork.greedy_scan), so
@@ -57,6 +76,27 @@ class RNNTModel(torch.nn.Module):
         assert mel_features.shape[0] == 1, "Greedy decoding only works with a batch size of 1"
         stateful = self._predictor_is_stateful()
         audio = self.encoder(mel_features).permute(0, 2, 1)
+        # device_loop (None: when possible): the WHOLE loop on the device — scan, argmax, the loop's bookkeeping and the
+        # ConvPredictor step per token as one fixed kernel sequence per iteration — and ONE host synchronisation per
+        # utterance (the scan path below still synchronises once per emitted token).
+        if device_loop is None:
+            device_loop = scan_frames > 0 and not stateful and self._device_loop_ok(audio)
+        if device_loop:
+            from . import engine
+            if stateful or not self._device_loop_ok(audio):
+                raise RuntimeError("greedy_decode(device_loop=True) needs the engine's stateless ConvPredictor in eval mode on a HIP device")
+            frames = audio[0]
+            if hasattr(self.joint, "audio_ln"):
+                frames = self.joint.audio_ln(frames)
+            frames = frames.float().contiguous()
+            tl = getattr(self.joint, "text_ln", None)
+            state, toks = engine.greedy_decode_loop(
+                frames, self.predictor._params(), float(self.predictor.output_layer_norm.eps),
+                tl.weight if tl is not None else None, tl.bias if tl is not None else None,
+                self.joint.joint_ln.weight, self.joint.joint_ln.bias, self.joint.blank_idx, max_length,
+                max_per_frame=10, scan_frames=max(1, min(int(scan_frames) if scan_frames > 0 else 64, 128)))
+            n = int(state[2].item())  # the utterance's one synchronisation
+            return toks[1:1 + n].tolist()
         tokens = [self.joint.blank_idx]
         dev = self.device
 

@@ -805,6 +805,49 @@ def test_greedy_decode_scan_matches_per_frame_loop(amd):
         assert model.greedy_decode(mel, lens, max_length=80, scan_frames=128) == b
 
 
+def test_greedy_decode_device_loop_matches_per_frame_loop(amd):
+    """RNNTModel.greedy_decode(device_loop=True): the WHOLE loop of rnnt/model.py:108-125 on the device
+    (rnnt_engine_greedy_decode: scan, argmax, bookkeeping, the ConvPredictor step per token computed incrementally
+    from rings of the last 7 positions; one host sync per utterance) decodes exactly what the reference's per-frame
+    loop decodes with the predictor re-run on the whole history — with and without audio_ln / text_ln, for block
+    sizes that split the utterance differently, when max_length cuts the loop, and when a frame hits the
+    10-symbols-per-frame cap."""
+    torch.manual_seed(5)
+
+    class Enc(torch.nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.c = torch.nn.Conv1d(10, c, 3, stride=2, padding=1)
+
+        def forward(self, x):
+            return self.c(x)
+
+        def calc_output_lens(self, lens):
+            return (lens + 1) // 2
+
+    V = 32
+    for fa, ft, hid, E, O, bias_blank in ((-1, -1, 64, 48, 64, 1.0), (40, 56, 72, 32, 56, 1.0), (-1, -1, 64, 48, 64, -2.0)):
+        pred = amd.ConvPredictor(V, O, E, 0.3)
+        model = amd.RNNTModel(pred, Enc(fa if fa > 0 else hid), amd.JointNetwork(fa, ft, hid, V)).cuda().eval()
+        with torch.no_grad():
+            model.joint.joint_ln.bias[V - 1] += bias_blank  # -2: blank rarely wins -> the 10-per-frame cap and max_length cut in
+        assert model._device_loop_ok(torch.zeros(1, 1, device="cuda"))
+        mel = torch.randn(1, 10, 150, device="cuda")
+        lens = torch.tensor([150], device="cuda")
+        for max_length in (60, 9):
+            want = model.greedy_decode(mel, lens, max_length=max_length, scan_frames=0)
+            assert 0 < len(want) <= max_length - 1
+            assert model.greedy_decode(mel, lens, max_length=max_length, scan_frames=16, device_loop=False) == want
+            for scan in (16, 64, 7, 128):
+                got = model.greedy_decode(mel, lens, max_length=max_length, scan_frames=scan, device_loop=True)
+                assert got == want, (fa, bias_blank, max_length, scan, got, want)
+        assert model.greedy_decode(mel, lens, max_length=60) == model.greedy_decode(mel, lens, max_length=60, scan_frames=0)  # default: the device loop
+    # training mode with dropout: the device loop is not the module's arithmetic any more -> refused, default falls back
+    model.train()
+    with pytest.raises(RuntimeError, match="device_loop"):
+        model.greedy_decode(mel, lens, max_length=20, device_loop=True)
+
+
 def test_greedy_decode_stateful_predictor_branch(amd):
     """RNNTModel.greedy_decode with a STATEFUL predictor — forward(ids, lens, state=None) ->
     (features, lens, state), fed the last token only (reference rnnt/model.py:45-87, the LSTMPredictor

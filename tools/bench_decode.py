@@ -34,3 +34,28 @@ for scan in (0, 16, 32, 64, 128):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"scan_frames={scan:3d}: {dt * 1e3:8.1f} ms, {len(toks)} tokens, {dt / T * 1e6:7.1f} us per audio frame", flush=True)
+
+# ---- round 4: the reference's real predictor (ConvPredictor: S=1024 symbols, E=512, O=1024, the fullcausal config's
+# dims; joint without projections needs O == H, so the joint is 1024 wide here) — per-frame loop and scan (predictor
+# re-run on the whole history per token, rnnt/model.py:103-123) against the device-resident loop
+# (rnnt_engine_greedy_decode: one host sync per utterance)
+print("ConvPredictor (E=512, O=1024), joint H=1024, V=1024:", flush=True)
+H2 = 1024
+pred2 = rnnt_amd.ConvPredictor(V, H2, 512, 0.3)
+model2 = rnnt_amd.RNNTModel(pred2, Enc(), rnnt_amd.JointNetwork(-1, -1, H2, V)).cuda().eval()
+with torch.no_grad():
+    model2.joint.joint_ln.bias[V - 1] += float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+mel2 = torch.randn(1, H2, T, device="cuda")
+for name, kw in (("per-frame loop", dict(scan_frames=0, device_loop=False)), ("scan 32", dict(scan_frames=32, device_loop=False)),
+                 ("scan 64", dict(scan_frames=64, device_loop=False)), ("device loop 32", dict(scan_frames=32, device_loop=True)),
+                 ("device loop 64", dict(scan_frames=64, device_loop=True)), ("device loop 128", dict(scan_frames=128, device_loop=True))):
+    model2.greedy_decode(mel2, lens, max_length=400, **kw)  # warm-up
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        toks = model2.greedy_decode(mel2, lens, max_length=400, **kw)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[1]
+    print(f"{name:16s}: {dt * 1e3:8.2f} ms, {len(toks)} tokens, {dt / T * 1e6:7.2f} us per audio frame", flush=True)

@@ -3,7 +3,7 @@ one child process per library.   python3 tools/exp_x3dh.py [config] [exp ...]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LABEL = {0: "shipped", 6: "no logits loads, no G stores", 16: "no epilogue", 8: "no W DMA", 1: "no MFMA", 22: "no loads / G stores / epilogue", 30: "MFMA + production + exchange only", 32768: "round-3 G stores (32-byte pieces)", 2: "no G stores", 4: "no logits loads", 32770: "round-3 kernel, no G stores"}
+LABEL = {0: "shipped", 99: "previous commit's x3.hip", 6: "no logits loads, no G stores", 16: "no epilogue", 8: "no W DMA", 1: "no MFMA", 22: "no loads / G stores / epilogue", 30: "MFMA + production + exchange only", 32768: "round-3 G stores (32-byte pieces)", 2: "no G stores", 4: "no logits loads", 32770: "round-3 kernel, no G stores"}
 
 
 def measure(cfg):
