@@ -25,6 +25,12 @@
 // around long MFMA streams (96 MFMAs = 3072 matrix-pipe cycles per 16-deep k-step), like the fp32 route's.
 #include "kernels.hpp"
 
+// compile-time experiment switches (tools/build_x3_variants.sh: -DX3_EXP=bits); the shipped build has none set
+#ifndef X3_EXP
+#define X3_EXP 0
+#endif
+#define X3_OFF(bit) ((X3_EXP) & (bit))
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -329,8 +335,18 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
 #pragma unroll
                         for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x3_mfma(fa[qm], fb[qn], acc[qm][qn]);
                     }
+                    if (X3_OFF(4194304)) {  // experiment: the 12 DMAs in the two products that follow no fragment-read burst (am.bm, ah.bl), six each
+                        constexpr int B0 = N0 == 4 ? 0 : 6;
+                        if (N0 == 4 || N0 == 10) {
+                            if (qm == 0) { dma_piece(X3Int<B0>{}); dma_piece(X3Int<B0 + 1>{}); }
+                            if (qm == 1) dma_piece(X3Int<B0 + 2>{});
+                            if (qm == 2) { dma_piece(X3Int<B0 + 3>{}); dma_piece(X3Int<B0 + 4>{}); }
+                            if (qm == 3) dma_piece(X3Int<B0 + 5>{});
+                        }
+                    } else {
                     if (qm == 1) dma_piece(X3Int<N0>{});
                     if (qm == 3) dma_piece(X3Int<N0 + 1>{});
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -464,10 +480,6 @@ void launch_dw_x3(const X3Args &a, hipStream_t st)
 // compile-time experiment switches (tools/build_x3_variants.sh: -DX3_EXP=bits; the run-time switches of the
 // RNNT_ABLATE build make hipcc spill 149 registers in this kernel): 1 no MFMA, 2 no G stores, 4 no raw loads in
 // the loop, 8 no W DMA, 16 no epilogue, 32 no production arithmetic, 64 no fragment reads
-#ifndef X3_EXP
-#define X3_EXP 0
-#endif
-#define X3_OFF(bit) ((X3_EXP) & (bit))
 #define XG_WAIT8_BUT(b, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
 #define XG_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
 // ---------------------------------------------------------------------------------------

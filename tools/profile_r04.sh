@@ -1,0 +1,43 @@
+#!/bin/bash
+# GPU box, round 4: everything profiles/r04_* is built from.  usage: bash tools/profile_r04.sh [part]
+#   part 1: bench lines (default = bf16x3 with exact_fp32 + CPU baseline; fp32; bf16; cfg4 / cfg5 / ref1024 on bf16x3; permuted enc)
+#   part 2: rocprofv3 kernel stats (bf16x3, bf16) + FETCH_SIZE / WRITE_SIZE passes (bf16x3)
+#   part 3: SQ counters of the bf16x3 kernels; bf16x3 shard timings (B = 32/16/8/4); decode bench + its kernel stats
+PART=${1:-all}
+TAG=r04
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+if [ "$PART" = 1 ] || [ "$PART" = all ]; then
+  timeout -k 10 400 python3 bench.py > gpurun_out/$TAG.default.json 2> gpurun_out/$TAG.default.err; echo "default rc=$?"
+  timeout -k 10 200 python3 bench.py --dtype fp32 --no-cpu-baseline > gpurun_out/$TAG.fp32.json 2>/dev/null; echo "fp32 rc=$?"
+  timeout -k 10 200 python3 bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/$TAG.bf16.json 2>/dev/null; echo "bf16 rc=$?"
+  timeout -k 10 200 python3 bench.py --permuted-enc --no-cpu-baseline --no-exact-fp32 > gpurun_out/$TAG.bf16x3.permuted.json 2>/dev/null; echo "permuted rc=$?"
+  timeout -k 10 200 python3 bench.py --config ref1024 --no-cpu-baseline --no-exact-fp32 > gpurun_out/$TAG.ref1024.bf16x3.json 2>/dev/null; echo "ref1024 rc=$?"
+  timeout -k 10 300 python3 bench.py --config cfg5 --steps 5 --warmup 2 --no-cpu-baseline --no-exact-fp32 > gpurun_out/$TAG.cfg5.json 2>/dev/null; echo "cfg5 rc=$?"
+  timeout -k 10 300 python3 bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --no-exact-fp32 > gpurun_out/$TAG.cfg4.json 2>/dev/null; echo "cfg4 rc=$?"
+fi
+if [ "$PART" = 2 ] || [ "$PART" = all ]; then
+  for DT in bf16x3 bf16; do
+    CMD="python3 bench.py --dtype $DT --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-exact-fp32"
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG.$DT/trace -- $CMD > gpurun_out/$TAG.$DT.trace.log 2>&1
+    echo "$DT trace rc=$?"
+    grep '"metric"' gpurun_out/$TAG.$DT.trace.log | tail -1 > gpurun_out/$TAG.$DT.under_rocprof.json
+    cp $(ls gpurun_out/$TAG.$DT/trace/*/*kernel_stats.csv | head -1) gpurun_out/$TAG.$DT.kernel_stats.csv
+  done
+  SHORT="python3 bench.py --dtype bf16x3 --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-stage-timing --no-exact-fp32"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 150 rocprofv3 --pmc $C --output-format csv -d gpurun_out/$TAG.bf16x3/$C -- $SHORT > gpurun_out/$TAG.bf16x3.$C.log 2>&1
+    echo "bf16x3 $C rc=$?"
+    python3 tools/pmc_summary.py $(ls gpurun_out/$TAG.bf16x3/$C/*/*counter_collection.csv | head -1) > gpurun_out/$TAG.bf16x3.$C.txt
+  done
+fi
+if [ "$PART" = 3 ] || [ "$PART" = all ]; then
+  SHORT="python3 bench.py --dtype bf16x3 --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-stage-timing --no-exact-fp32"
+  timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/$TAG.bf16x3/SQ -- $SHORT > gpurun_out/$TAG.bf16x3.SQ.log 2>&1
+  echo "bf16x3 SQ rc=$?"
+  python3 tools/pmc_summary.py $(ls gpurun_out/$TAG.bf16x3/SQ/*/*counter_collection.csv | head -1) > gpurun_out/$TAG.bf16x3.SQ.txt
+  timeout -k 10 300 python3 tools/exp_batch_scaling.py bf16x3 > gpurun_out/$TAG.batch_scaling_bf16x3.txt 2>&1; echo "scaling rc=$?"
+  timeout -k 10 200 python3 tools/bench_decode.py 1.6 1.9 > gpurun_out/$TAG.bench_decode.txt 2>&1; echo "decode rc=$?"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG.f_decode/trace -- python3 tools/bench_decode.py 1.6 1.9 > gpurun_out/$TAG.f_decode.trace.log 2>&1
+  cp $(ls gpurun_out/$TAG.f_decode/trace/*/*kernel_stats.csv | head -1) gpurun_out/$TAG.f_decode.kernel_stats.csv; echo "decode trace rc=$?"
+fi
