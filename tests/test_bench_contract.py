@@ -53,6 +53,24 @@ def test_committed_bf16_bench_line(rnd):
         assert d["steps"] == 20
 
 
+def test_committed_round4_default_bench_line():
+    """The shipped default (bf16x3 arithmetic, fp32-accurate): the line carries the exact-fp32 route timed in the same run, the
+    MFMA-busy figure replayed from the committed SQ counter pass, and names its ranks by transport."""
+    d = _line("r04_bench_default.json")
+    _check(d, "f32")
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 6.0) < 1e-6 and r["traffic"] > 0
+    assert 0.3 < r["mfma_busy"] < 1.0 and r["mfma_busy_source"]["replayed"] is True
+    assert os.path.exists(os.path.join(ROOT, r["mfma_busy_source"]["file"])) and os.path.exists(os.path.join(ROOT, r["traffic_source"]["file"]))
+    e = d["exact_fp32"]
+    assert e["peak"] == 157.3 and abs(e["frac"] - e["path_tflops"] / 157.3) < 1e-9 and e["ms_per_step"] > d["ms_per_step"]
+    assert abs(e["loss"] - d["loss"]) <= 1e-4 * abs(d["loss"])  # the two arithmetic forms agree on the same inputs
+    assert d["rccl_ranks"] == 0 and "dist_ranks" not in d and d["steps"] == 20
+    assert d["parity"]["loss_rel_err"] < 1e-4 and d["parity"]["grad_rel_err"] < 1e-4
+    c4 = _line("r04_cfg4_bf16x3_bench.json")  # config 4 on the shipped default route: a kept record
+    assert "cfg4" in c4["config"]["workload"] and "bf16x3" in c4["config"]["workload"] and c4["ms_per_step"] > 0
+
+
 def test_bench_refuses_to_run_fewer_gpus_than_asked():
     """`python bench.py --gpus N` with no launcher (WORLD_SIZE unset) starts the N ranks itself and
     must exit non-zero — never fall through to a 1-GPU run — when fewer than N devices exist."""
