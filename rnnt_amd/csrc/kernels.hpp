@@ -162,7 +162,8 @@ void launch_joint_fwd_x3(const X3Args &a, hipStream_t st);   // one 512-register
 bool x3_fwd_d_ok(int U1, int H, int V);
 void launch_joint_fwd_x3d(const X3Args &a, int nw, hipStream_t st);  // two waves per SIMD, A in registers (RNNT_VARIANT_X3_FWD_2WG / _8W)
 void launch_dhidden_x3(const X3Args &a, hipStream_t st);
-void launch_dw_x3(const X3Args &a, hipStream_t st);
+void launch_dw_x3(const X3Args &a, hipStream_t st);   // v_mfma_f32_32x32x16_bf16, six products per k-step (default)
+void launch_dw_x3p(const X3Args &a, hipStream_t st);  // v_mfma_f32_16x16x32_bf16, two products per MFMA (RNNT_VARIANT_X3_DW_P16)
 
 // ---- decode.hip
 void launch_scan_logits(const float *enc, long enc_st, const float *pred, const float *W, const float *bias,

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
                                                           (int)(XW_ROWS * rstride[p]), 0x00020000);
             auto dma_piece = [&](auto n_c) {  // piece n of stage ks+2 -> ring stage DST: plane n>>2, rows 4(n&3)..
                 constexpr int n = decltype(n_c)::value, p = n >> 2, i = n & 3;
-                if (RNNT_XP(a.flags, 8192)) return;
+                if (RNNT_XP(a.flags, 8192) || X3_OFF(8)) return;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + wave * XW_TILE + DST * XW_STAGE + p * XW_PLANE + 1024 * i),
                                                          16, soff[p][i], 0, 0, 0);
             };
@@ -476,6 +476,299 @@ void launch_dw_x3(const X3Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_dw_x3, dim3(tiles * a.n_split), dim3(256), 4 * XW_TILE, st, a);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_dw_x3p (round 4): k_dw_x3 on v_mfma_f32_16x16x32_bf16 — the shape on which the chip holds a higher clock
+// under a dense bf16 matrix stream (tools/mfma_shape.hip: 1.96-2.03 GHz against 1.74-1.83 for 32x32x16 at equal
+// cycles per flop) — WITHOUT its 32-deep k-step: one k = 32 MFMA carries TWO of the six products of a 16-cell
+// k-step.  Its A operand's k = 0..15 come from one plane, k = 16..31 from another (lane groups 2, 3 simply address
+// the other plane's rows of the same ring stage), likewise B:
+//     P0 = [g_hi | g_mid] . [h_hi | h_hi]   = g_hi.h_hi  + g_mid.h_hi
+//     P1 = [g_hi | g_mid] . [h_mid | h_mid] = g_hi.h_mid + g_mid.h_mid
+//     P2 = [g_hi | g_lo ] . [h_lo | h_hi ]  = g_hi.h_lo  + g_lo.h_hi
+// — the same six products, three MFMAs of 16 cycles per 16x16 tile instead of six of 32 per 32x32 tile: equal
+// matrix-pipe cycles, same ring, same DMAs, same k-steps.  P0 and P1 share their A fragments.
+// MEASURED (tools/exp_x3dw.py, interleaved rounds in one process): 26.99 ms against k_dw_x3's 27.03 — the shape's clock
+// advantage of the bare loop does not appear in the kernel (with the DMAs compiled out: 21.4 against 20.3 ms: twice the
+// fragment reads and half the issue slack per MFMA cost what the shape gives).  Kept behind RNNT_VARIANT_X3_DW_P16.
+// Wave tile 128 v x 128 h = 8 x 8 tiles of 16 x 16 (256 accumulator registers).  Fragment of a 16-column tile:
+// lane (g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3) reads rows 8 (g & 1) + 4 sec + q (sec = 0, 1) at chunk
+// 2 mt + (p >> 1), + 8 (p & 1) bytes, of plane X (g < 2) or Y (g >= 2): two ds_read_b64_tr_b16 = the lane's 8 cells
+// of column 16 mt + (lane & 15).  The plane of groups 0, 1 is an instruction immediate, the Y - X distance is added
+// to the base of groups 2, 3 per read (one v_add: base sets per distance spill).  The MFMAs are inline asm on "+a"
+// accumulators: left to hipcc the 64 four-register tiles wander between the register files from k-step to k-step
+// (172 v_accvgpr_write + 172 _read + 80 _mov per k-step in its own schedule).
+// db: [g_hi | g_mid] and [g_hi | g_lo] against selector fragments (ones in one column; for the second: only its k >= 16 half).
+// ---------------------------------------------------------------------------------------
+struct X3PFrag { u32x2 lo[8], hi[8]; };  // 8 tiles of 16 columns: cells 0-3 / 4-7 of the lane's 8
+#define X3P_LANDED(f, N)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                         \
+                 : "+v"(f.lo[0]), "+v"(f.lo[1]), "+v"(f.lo[2]), "+v"(f.lo[3]), "+v"(f.lo[4]), "+v"(f.lo[5]), "+v"(f.lo[6]),  \
+                   "+v"(f.lo[7]), "+v"(f.hi[0]), "+v"(f.hi[1]), "+v"(f.hi[2]), "+v"(f.hi[3]), "+v"(f.hi[4]), "+v"(f.hi[5]),  \
+                   "+v"(f.hi[6]), "+v"(f.hi[7])                                                                      \
+                 :: "memory")
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__global__ __launch_bounds__(256, 1) void k_dw_x3p(X3Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) char s_ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.H, V = a.V;
+    const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
+    const int tiles = n_vblk * n_hblk;
+    const int total = tiles * a.n_split;
+    int id = blockIdx.x;  // XCD-aware remap: the tiles of one split share an XCD's L2
+    {
+        const int q8 = total / 8, r8 = total % 8, x = id % 8;
+        id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + id / 8;
+    }
+    const int tile = id % tiles, split = id / tiles;
+    const int vb = tile / n_hblk, hb = tile % n_hblk;
+    const long *tab = a.dw_tab;
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+
+    f32x4_t acc[8][8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(acc[mt][nt]));  // (an accumulator-file value from here on)
+        }
+    // db: the wave's M tile(s) of 32 v (k_dw_x3's assignment) = two 16-row tiles each -> selector columns 0, 1 (2, 3)
+    const bool do_b = hb < 2;  // workgroup-uniform
+    const int bsel0 = n_hblk >= 2 ? (hb & 1) * 2 + wn : wn;
+    const int ntl = n_hblk < 2 ? 4 : 2;
+    f32x4_t dacc = {0.f, 0.f, 0.f, 0.f};
+    const int g4 = lane >> 4;
+
+    if (g_hi > g_lo) {
+        // ---- DMA source of this wave's operand tile (as k_dw_x3)
+        const bool is_g = wave < 2;
+        int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
+        if (col0 >= (is_g ? V : H)) col0 = 0;
+        const char *pbase[3];
+        long rstride[3];
+        if (is_g) {
+            pbase[0] = (const char *)a.logits + 4L * col0;
+            pbase[1] = (const char *)a.logits + 4L * col0 + 64;
+            pbase[2] = (const char *)a.g_lo + 2L * col0;
+            rstride[0] = rstride[1] = 4L * V; rstride[2] = 2L * V;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { pbase[p] = (const char *)(a.hidden + p * a.plane_stride) + 2L * col0; rstride[p] = 2L * H; }
+        }
+        int soff[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jg = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
+                const int cb = (is_g && p < 2) ? 128 * (jg >> 2) + 16 * (jg & 3) : 16 * jg;
+                soff[p][i] = (int)((4 * i + (lane >> 4)) * rstride[p]) + cb;
+            }
+        long row_first = 0;
+        // ---- fragment read bases: one per (tile, sec) and operand; groups 2, 3 add the distance to their plane per read
+        const int q = (lane & 15) >> 2, pp = lane & 3;
+        const int lds0 = (int)(size_t)(lds_vptr)s_ring;
+        const int upper = g4 >= 2 ? 1 : 0;
+        const int dP1 = upper * XW_PLANE, dP2 = upper * 2 * XW_PLANE, dM2 = -upper * 2 * XW_PLANE;
+        auto frag_off = [&](int mt, int sec) {
+            const int row = 8 * (g4 & 1) + 4 * sec + q;
+            const int ch = 2 * mt + (pp >> 1);
+            const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+            return 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+        };
+        int aB[8][2], bB[8][2];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                aB[mt][sec] = lds0 + wm * XW_TILE + frag_off(mt, sec);
+                bB[mt][sec] = lds0 + (2 + wn) * XW_TILE + frag_off(mt, sec);
+            }
+        int sB[4][2];  // db: the (up to four) 16-row tiles this wave sums, read once more through their own bases
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) sB[kk][sec] = lds0 + wm * XW_TILE + frag_off((2 * (bsel0 + 2 * (kk >> 1)) + (kk & 1)) & 7, sec);
+        const unsigned one2 = 0x3f803f80u;
+        auto selv = [&](int col, bool upper_only) { return ((lane & 15) == col && (!upper_only || g4 >= 2)) ? one2 : 0u; };
+
+        auto kstep = [&](auto st_c, long ks, f32x4_t &dacc) {
+            constexpr int ST = decltype(st_c)::value, DST = (ST + 2) % 3;
+            __amdgpu_buffer_rsrc_t rs[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                rs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (ks + 2) * XW_ROWS) * rstride[p]), 0,
+                                                          (int)(XW_ROWS * rstride[p]), 0x00020000);
+            auto dma_piece = [&](auto n_c) {  // piece n of stage ks+2 -> ring stage DST: plane n>>2, rows 4(n&3)..
+                constexpr int n = decltype(n_c)::value, p = n >> 2, i = n & 3;
+                if (X3_OFF(8)) return;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + wave * XW_TILE + DST * XW_STAGE + p * XW_PLANE + 1024 * i),
+                                                         16, soff[p][i], 0, 0, 0);
+            };
+            // the 2 transposed reads of one fragment; PX: the plane of lane groups 0, 1 (an immediate); delta: groups 2, 3's plane distance
+            auto read2 = [&](u32x2 &lo, u32x2 &hi, int b0, int b1, int delta, auto px_c) {
+                constexpr int off = ST * XW_STAGE + decltype(px_c)::value * XW_PLANE;
+                const int c0 = b0 + delta, c1 = b1 + delta;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(c0), "n"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(c1), "n"(off));
+            };
+            auto read_tile = [&](X3PFrag &f, const int (&base)[8][2], int delta, auto px_c, int t) {
+                read2(f.lo[t], f.hi[t], base[t][0], base[t][1], delta, px_c);
+            };
+            auto frag = [&](const X3PFrag &f, int t) { return u32x4{f.lo[t][0], f.lo[t][1], f.hi[t][0], f.hi[t][1]}; };
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            x3_lds_barrier();
+            // three fragment sets: A = [hi | mid] for P0 and P1, refilled IN PLACE with [hi | lo] during P1 (one tile row behind
+            // the MFMAs that read it); Bx = [hi | hi] for P0, refilled with [lo | hi] during P1; By = [mid | mid]
+            X3PFrag A, Bx, By;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { read_tile(A, aB, dP1, X3Int<0>{}, t); read_tile(Bx, bB, 0, X3Int<0>{}, t); }
+            X3P_LANDED(A, 0);
+            X3P_LANDED(Bx, 0);
+            // one pair product: 64 MFMAs, a filler slot after each of its 8 tile rows
+            auto pair = [&](X3PFrag &fa, const X3PFrag &fb, auto which_c) {
+                constexpr int W = decltype(which_c)::value;
+                u32x4 bv[8];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) bv[nt] = frag(fb, nt);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const u32x4 av = frag(fa, mt);
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(av), "v"(bv[nt]));
+                    if (W == 0) {  // beside P0: B = [mid | mid] of this k-step; DMA pieces 0-3
+                        read_tile(By, bB, 0, X3Int<1>{}, mt);
+                        if (mt == 1) dma_piece(X3Int<0>{});
+                        if (mt == 3) dma_piece(X3Int<1>{});
+                        if (mt == 5) dma_piece(X3Int<2>{});
+                        if (mt == 7) dma_piece(X3Int<3>{});
+                    } else if (W == 1) {  // beside P1: A <- [hi | lo] (one row behind), B <- [lo | hi]; DMA pieces 4-7
+                        if (mt >= 1) read_tile(fa, aB, dP2, X3Int<0>{}, mt - 1);
+                        read_tile(Bx, bB, dM2, X3Int<2>{}, mt);
+                        if (mt == 1) dma_piece(X3Int<4>{});
+                        if (mt == 3) dma_piece(X3Int<5>{});
+                        if (mt == 5) dma_piece(X3Int<6>{});
+                        if (mt == 7) dma_piece(X3Int<7>{});
+                    } else {  // beside P2: DMA pieces 8-11
+                        if (mt == 1) dma_piece(X3Int<8>{});
+                        if (mt == 3) dma_piece(X3Int<9>{});
+                        if (mt == 5) dma_piece(X3Int<10>{});
+                        if (mt == 7) dma_piece(X3Int<11>{});
+                    }
+                }
+            };
+            pair(A, Bx, X3Int<0>{});
+            X3P_LANDED(By, 0);
+            pair(A, By, X3Int<1>{});
+            read_tile(A, aB, dP2, X3Int<0>{}, 7);
+            X3P_LANDED(A, 0);
+            X3P_LANDED(Bx, 0);
+            if (do_b) {  // db[v] += sum over the 16 cells of hi + mid ([hi | mid] against all-k ones) and of lo ([hi | lo] against k >= 16 ones)
+                u32x2 l01[4], h01[4], l2[4], h2[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (kk < ntl) {
+                        read2(l01[kk], h01[kk], sB[kk][0], sB[kk][1], dP1, X3Int<0>{});
+                        read2(l2[kk], h2[kk], sB[kk][0], sB[kk][1], dP2, X3Int<0>{});
+                    }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (kk < ntl) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l01[kk]), "+v"(h01[kk]), "+v"(l2[kk]), "+v"(h2[kk]) :: "memory");
+                        const u32x4 f01 = {l01[kk][0], l01[kk][1], h01[kk][0], h01[kk][1]}, f2 = {l2[kk][0], l2[kk][1], h2[kk][0], h2[kk][1]};
+                        const unsigned s_all = selv(kk, false), s_up = selv(kk, true);
+                        const u32x4 sa = {s_all, s_all, s_all, s_all}, su = {s_up, s_up, s_up, s_up};
+                        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(dacc) : "v"(f01), "v"(sa));
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(dacc) : "v"(f2), "v"(su));
+                    }
+            }
+            pair(A, Bx, X3Int<2>{});
+        };
+        auto dma_stage = [&](long ks, int st) {  // pipeline prologue: all 12 pieces of stage ks
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int p = n >> 2, i = n & 3;
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(pbase[p] + (row_first + ks * XW_ROWS) * rstride[p]), 0, (int)(XW_ROWS * rstride[p]), 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(s_ring + wave * XW_TILE + st * XW_STAGE + p * XW_PLANE + 1024 * i),
+                                                         16, soff[p][i], 0, 0, 0);
+            }
+        };
+
+        int ub = 0;
+        while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;
+        for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
+            const long cum0 = tab[B + 1 + ub], cum1 = ub + 1 < B ? tab[B + 1 + ub + 1] : nlive;
+            const long ge = cum1 < g_hi ? cum1 : g_hi;
+            if (ge <= gq) continue;
+            const long nks = 2 * (ge - gq);  // 16-cell k-steps of this range
+            row_first = (tab[ub] + (gq - cum0)) * XW_GRAN;
+            gq = ge;
+            dma_stage(0, 0);
+            dma_stage(1, 1);
+            for (long ks = 0;;) {  // the ring stage of a k-step is ks % 3: unrolled by 3
+                if (ks >= nks) break;
+                kstep(X3Int<0>{}, ks, dacc); ++ks;
+                if (ks >= nks) break;
+                kstep(X3Int<1>{}, ks, dacc); ++ks;
+                if (ks >= nks) break;
+                kstep(X3Int<2>{}, ks, dacc); ++ks;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x3_lds_barrier();
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the last MFMAs' results (asm: hipcc pads nothing) before the accumulators are read below
+
+    // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r of tile (mt, nt):
+    // v = v0 + 16 mt + 4 (lane >> 4) + r, h = h0 + 16 nt + (lane & 15).
+    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
+    float *sw = a.slab_w + (long)split * V * H;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + 16 * mt + 4 * g4 + r;
+            if (v < V) {
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const int h = h0 + 16 * nt + (lane & 15);
+                    if (h < H) sw[(long)v * H + h] = acc[mt][nt][r];
+                }
+            }
+        }
+    if (do_b && (lane & 15) < ntl) {  // column k of the selector products holds the sums of 16-row tile k of this wave's share
+        const int k = lane & 15;
+        const int mt = 2 * (bsel0 + 2 * (k >> 1)) + (k & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + 16 * mt + 4 * g4 + r;
+            if (v < V) a.slab_b[(long)split * V + v] = dacc[r];
+        }
+    }
+}
+
+void launch_dw_x3p(const X3Args &a, hipStream_t st)
+{
+    launch_dw_table(a.logit_lens, a.B, a.T, a.U1, XW_GRAN, a.dw_tab, st);
+    const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_dw_x3p, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW_TILE);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_dw_x3p, dim3(tiles * a.n_split), dim3(256), 4 * XW_TILE, st, a);
+}
 
 // compile-time experiment switches (tools/build_x3_variants.sh: -DX3_EXP=bits; the run-time switches of the
 // RNNT_ABLATE build make hipcc spill 149 registers in this kernel): 1 no MFMA, 2 no G stores, 4 no raw loads in

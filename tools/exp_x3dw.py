@@ -12,17 +12,18 @@ def measure(cfg):
     enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
     outs = engine.alloc_fused_outputs(enc, pred, W)
 
-    def run(mask):
-        engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, dtype="bf16x3", stage_mask=mask)
+    def run(mask, var=0):
+        engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, dtype="bf16x3", stage_mask=mask, variant=var)
 
     run(255)
-    ts = []
-    for _ in range(5):
-        run(64)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); run(64); run(64); e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_time(e1) / 2)
-    return f"dw {sorted(ts)[2]:7.3f} ms (min {min(ts):7.3f})"
+    res = {}
+    for _ in range(5):  # interleaved rounds: the 16x16x32 pair form (default) against the 32x32x16 kernel
+        for name, var in (("pair16", engine.VARIANT_X3_DW_P16), ("v1_32", 0)):
+            run(64, var)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); run(64, var); run(64, var); e1.record(); e1.synchronize()
+            res.setdefault(name, []).append(e0.elapsed_time(e1) / 2)
+    return "  ".join(f"dw[{n}] {sorted(v)[2]:7.3f} ms (min {min(v):7.3f})" for n, v in res.items())
 
 
 if __name__ == "__main__":
