@@ -242,7 +242,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     const int xflags = g_flags | (variant & (RNNT_VARIANT_SEPARATE_G | RNNT_VARIANT_SEPARATE_HIDDEN |
                                              RNNT_VARIANT_FWD_LDS_RING | RNNT_VARIANT_FWD_ONE_WG_PER_TILE |
                                              RNNT_VARIANT_X3_FP32_FWD | RNNT_VARIANT_X3_FP32_DH |
-                                             RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16));
+                                             RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z));
     rnnt_engine_ws_layout L;
     layout(B, T, U1, H, V, dtype, &L);
     if (ws_bytes < L.total)
@@ -325,7 +325,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
                 f.make_hidden = 1; f.counter = h.counter; f.n_cu = h.n_cu;
                 launch_joint_fwd(f, st);
                 launch_x3_make_hidden(h, st);  // the planes the backward reads
-            } else if ((xflags & (RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16)) && x3_fwd_d_ok(U1, H, V)) {
+            } else if ((xflags & (RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z)) && x3_fwd_d_ok(U1, H, V)) {
                 launch_joint_fwd_x3d(h, (xflags & RNNT_VARIANT_X3_FWD_8W) ? 8 : 4, st);
             } else {
                 launch_joint_fwd_x3(h, st);

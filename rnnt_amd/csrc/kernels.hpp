@@ -160,6 +160,7 @@ void launch_x3_zero_padding(const X3Args &a, int what, hipStream_t st);
 void launch_x3_pack_w(const X3Args &a, hipStream_t st);
 void launch_joint_fwd_x3(const X3Args &a, hipStream_t st);   // one 512-register wave per SIMD (default)
 bool x3_fwd_d_ok(int U1, int H, int V);
+void launch_joint_fwd_x3z(const X3Args &a, hipStream_t st);  // one wave per SIMD, 2 M tiles per wave, 256 x 256 tiles, A in registers (RNNT_VARIANT_X3_FWD_Z)
 void launch_joint_fwd_x3d(const X3Args &a, int nw, hipStream_t st);  // two waves per SIMD, A in registers (RNNT_VARIANT_X3_FWD_2WG / _8W)
 void launch_dhidden_x3(const X3Args &a, hipStream_t st);
 void launch_dw_x3(const X3Args &a, hipStream_t st);   // v_mfma_f32_32x32x16_bf16, six products per k-step (default)

@@ -1598,6 +1598,332 @@ void launch_joint_fwd_x3d(const X3Args &a, int nw, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------
+// k_joint_fwd_x3z (round 4): k_joint_fwd_x3d's wave — A in registers, 256-column passes, W through a 3-slot ring two
+// k-steps ahead — with TWO 32-row M tiles per wave: 4 waves, ONE per SIMD (2 x 8 accumulator tiles = 256 registers), a tile
+// of 256 cells per 24 KiB W k-step.  What it is for: the measurements of this round price a W DMA at ~1.2 ms of the kernel
+// per DMA and k-step, whichever wave issues it; this form issues 6 per wave and k-step of 96 MFMAs where k_joint_fwd_x3
+// issues 12 (half the W bytes per MFMA: the tile is 256 x 256 instead of 128 x 512), needs no A exchange (no ds_write, 24
+// fragment reads per k-step instead of 30) and pays with hidden being produced in four passes instead of two.
+// Per k-step and wave: 96 MFMAs (tile q: 3 fragment reads, 6 products x 2 M tiles), 6 DMAs, 8 operand loads, 2 x 16
+// production pieces, 6 hidden stores (first pass) — in the fixed order D x6, L x8, S x6.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_joint_fwd_x3z(X3Args a, const int ntiles)
+{
+    constexpr int ROWS = 256, ND = 6;
+    extern __shared__ __attribute__((aligned(1024))) char s_fz[];
+    float *s_den = (float *)(s_fz + XD_NSLOT * XD_WSLOT);
+    float *s_part = s_den + ROWS;  // [row][max, sum]
+    int *s_next = (int *)(s_part + 2 * ROWS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int H = a.H, V = a.V, KC = H / 16, U1 = a.U1, T = a.T;
+    const int npass = (V + 255) / 256;
+    const long cells = (long)a.B * T * U1;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+
+    const int lds0 = (int)(size_t)(lds_vptr)s_fz;
+    const int wb = lds0 + 16 * lane;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, ((V + 511) / 512) * KC * 49152, 0x00020000);
+    const int wvo = lane * 16;
+
+    if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    int tile = s_next[0];
+    for (int it = 1; tile < ntiles; ++it) {
+        if (tid == 0) s_next[it & 1] = (int)atomicAdd(a.counter, 1u);
+        const long row0 = (long)tile * ROWS;
+        s_part[2 * tid] = RNNT_NEG_INF; s_part[2 * tid + 1] = 0.f;  // 256 threads = 256 rows
+        __syncthreads();
+        const int next = s_next[it & 1];
+        bool dead;
+        {
+            const long per = (long)T * U1, c_last = row0 + ROWS - 1;
+            const long b_first = row0 / per;
+            dead = c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T);
+        }
+        // the wave's two M tiles: rows 32 (2 wave + m) + i of the tile
+        const float *ep[2], *pp[2];
+        u32x4 *hdst[2];
+        bool rows_exist[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const long prow = row0 + 32 * (2 * wave + m) + i;
+            rows_exist[m] = row0 + 32 * (2 * wave + m) < a.rows_alloc;  // wave-uniform
+            const long pc_ = prow < cells ? prow : cells - 1;
+            const int pu = (int)(pc_ % U1);
+            const long pbt = pc_ / U1;
+            const int pt = (int)(pbt % T), pb = (int)(pbt / T);
+            ep[m] = a.enc + (long)pb * a.enc_sb + (long)pt * a.enc_st + 8 * half;
+            pp[m] = a.pred + ((long)pb * U1 + pu) * H + 8 * half;
+            hdst[m] = (u32x4 *)a.hidden + pc_ * (H / 8) + half;
+        }
+        const long ps = a.plane_stride / 8;
+        struct Opd { f32x4 e0, e1, p0, p1; };
+        struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm, pl; };
+        auto op_load1 = [&](Opd &o, int m, int kcs, int k) {
+            if (k == 0) o.e0 = *(const f32x4 *)(ep[m] + 16 * kcs);
+            else if (k == 1) o.e1 = *(const f32x4 *)(ep[m] + 16 * kcs + 4);
+            else if (k == 2) o.p0 = *(const f32x4 *)(pp[m] + 16 * kcs);
+            else o.p1 = *(const f32x4 *)(pp[m] + 16 * kcs + 4);
+        };
+        auto prod_piece = [&](Prod &P, const Opd &o, int k) {  // (k_joint_fwd_x3d's pieces)
+            if (k < 8) {
+                const int j = k >> 1;
+                if (!(k & 1)) {
+                    const f32x4 &e = j < 2 ? o.e0 : o.e1, &pv = j < 2 ? o.p0 : o.p1;
+                    const int q = 2 * (j & 1);
+                    const f2 x = {e[q] + pv[q], e[q + 1] + pv[q + 1]};
+                    const f2 av = x * (2.0f * RNNT_LOG2E);
+                    P.w[j] = f2{__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+                } else {
+                    const f2 ex = P.w[j] + 1.0f;
+                    const f2 rr = {__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+                    P.w[j] = 1.0f - 2.0f * rr;
+                }
+            } else {
+                const int j = (k - 8) >> 1;
+                if (!(k & 1)) {
+                    const unsigned hh = x3_pack(P.w[j][0], P.w[j][1]);
+                    P.ph[j] = hh;
+                    P.ra = P.w[j][0] - x3_lo(hh); P.rb = P.w[j][1] - x3_hi(hh);
+                } else {
+                    const unsigned mm = x3_pack(P.ra, P.rb);
+                    P.pm[j] = mm;
+                    P.pl[j] = x3_pack(P.ra - x3_lo(mm), P.rb - x3_hi(mm));
+                }
+            }
+        };
+        auto wdma = [&](int base, int slot, int n) {
+            const int pc = wave * ND + n;  // 0..23: plane pc >> 3, tile pc & 7
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fz + slot * XD_WSLOT + pc * 1024), 16, wvo,
+                                                     base + (pc >> 3) * 16384 + (pc & 7) * 1024, 0, 0);
+        };
+        auto wbase = [&](int p, int kc) { return ((p >> 1) * KC + kc) * 49152 + (p & 1) * 8192; };
+
+        if (dead) {
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    Opd o; Prod P;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) op_load1(o, m, kc, k);
+#pragma unroll
+                    for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, pc);
+                    hdst[m][2 * kc] = P.ph; hdst[m][2 * kc + ps] = P.pm; hdst[m][2 * kc + 2 * ps] = P.pl;
+                }
+            tile = next;
+            continue;
+        }
+
+        f32x16 acc[2][8];
+        u32x4 Ah[2], Am[2], Al[2];
+        Opd oset[2][2];  // [k-step parity][M tile]
+        {
+#pragma unroll
+            for (int n = 0; n < ND; ++n) wdma(wbase(0, 0), 0, n);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) wdma(KC > 1 ? wbase(0, 1) : wbase(0, 0), 1, n);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Opd o; Prod P;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) op_load1(o, m, 0, k);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) op_load1(oset[1][m], m, KC > 1 ? 1 : 0, k);
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, pc);
+                hdst[m][0] = P.ph; hdst[m][ps] = P.pm; hdst[m][2 * ps] = P.pl;
+                Ah[m] = P.ph; Am[m] = P.pm; Al[m] = P.pl;
+            }
+        }
+        int cs = 0, slot = 0;
+        int pd = KC > 2 ? 0 : 1, kd = KC > 2 ? 2 : 0;
+        if (pd >= npass) { pd = npass - 1; kd = KC - 1; }
+
+        auto run_pass = [&](auto store_c, const int pass) {
+          constexpr bool STORE = decltype(store_c)::value != 0;
+          {
+            const int c0 = 256 * pass + 4 * i;
+            const f32x4 b0 = c0 < V ? *(const f32x4 *)(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = c0 + 128 < V ? *(const f32x4 *)(a.bias + c0 + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][q][r] = q < 4 ? b0[q] : b1[q - 4];
+          }
+          for (int kc0 = 0; kc0 < KC; kc0 += 2)
+#pragma unroll
+          for (int par = 0; par < 2; ++par, ++cs) {
+            const int kc = kc0 + par;
+            // W of k-step cs landed: its DMAs were issued during k-step cs-2; younger: L x8 + S x6 of k-step cs-2, D x6 + L x8 + S x6 of cs-1
+            if (kc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STORE) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            x3_lds_barrier();
+            const int ws = wb + slot * XD_WSLOT;
+            const int dslot = slot == 0 ? 2 : slot - 1;
+            const int dbase = wbase(pd, kd);
+            const int kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
+            const Opd (&ocur)[2] = oset[(par + 1) & 1];
+            Opd (&onext)[2] = oset[par & 1];
+            Prod P[2];
+            u32x4 b0[3], b1[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[p]) : "v"(ws), "n"(p * 8192));
+            // the fillers between the 96 MFMAs of the k-step, by slot index s = 12 q + 2 product + m
+            auto filler = [&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                if (s < 12) { if (!(s & 1)) wdma(dbase, dslot, s >> 1); }                        // D x6: k-step cs+2
+                else if (s < 20) op_load1(onext[(s - 12) >> 2], (s - 12) >> 2, kcnn, (s - 12) & 3);  // L x8: operands of k-step cs+2
+                else if (s < 84) {
+                    if (!(s & 1)) prod_piece(P[(s - 20) >> 5], ocur[(s - 20) >> 5], ((s - 20) >> 1) & 15);  // A of k-step cs+1: 2 x 16 pieces
+                    else if (STORE) {  // S x3 of M tile 0 behind its last piece (s = 50)
+                        if (s == 51) hdst[0][2 * kcn] = P[0].ph;
+                        if (s == 53) hdst[0][2 * kcn + ps] = P[0].pm;
+                        if (s == 55) hdst[0][2 * kcn + 2 * ps] = P[0].pl;
+                    }
+                } else if (STORE) {  // S x3 of M tile 1 (its last piece: s = 82)
+                    if (s == 85) hdst[1][2 * kcn] = P[1].ph;
+                    if (s == 87) hdst[1][2 * kcn + ps] = P[1].pm;
+                    if (s == 89) hdst[1][2 * kcn + 2 * ps] = P[1].pl;
+                }
+            };
+            auto tile_q = [&](auto q_c, const u32x4 (&bc)[3], u32x4 (&bn)[3]) {
+                constexpr int q = decltype(q_c)::value;
+                if (q < 7) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[p]) : "v"(ws), "n"(p * 8192 + (q < 7 ? q + 1 : 0) * 1024));
+                }
+#define XZ_MM(PI, AX, BP)                                                                   \
+                acc[0][q] = x3_mfma(AX[0], bc[BP], acc[0][q]);                              \
+                filler(X3Int<12 * q + 2 * (PI)>{}); __builtin_amdgcn_sched_barrier(0);      \
+                acc[1][q] = x3_mfma(AX[1], bc[BP], acc[1][q]);                              \
+                filler(X3Int<12 * q + 2 * (PI) + 1>{}); __builtin_amdgcn_sched_barrier(0);
+                XZ_MM(0, Ah, 0) XZ_MM(1, Am, 0) XZ_MM(2, Al, 0) XZ_MM(3, Ah, 1) XZ_MM(4, Am, 1) XZ_MM(5, Ah, 2)
+#undef XZ_MM
+                if (q < 7) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            tile_q(X3Int<0>{}, b0, b1); tile_q(X3Int<1>{}, b1, b0); tile_q(X3Int<2>{}, b0, b1); tile_q(X3Int<3>{}, b1, b0);
+            tile_q(X3Int<4>{}, b0, b1); tile_q(X3Int<5>{}, b1, b0); tile_q(X3Int<6>{}, b0, b1); tile_q(X3Int<7>{}, b1, b0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { Ah[m] = P[m].ph; Am[m] = P[m].pm; Al[m] = P[m].pl; }
+            slot = slot == 2 ? 0 : slot + 1;
+            if (++kd == KC) { kd = 0; ++pd; }
+            if (pd >= npass) { pd = npass - 1; kd = KC - 1; }
+          }
+          // pass complete: store the logits, update the statistics (as k_joint_fwd_x3d, per M tile)
+          const int cw = 256 * pass;
+          const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
+          char *tile_base = (char *)(a.logits + row0 * V + cw);
+          auto epilogue = [&](auto both_c) {
+              constexpr bool BOTH = decltype(both_c)::value != 0;
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float x0, x1;  // (volatile asm: the reads stay here, one row slot at a time; left to hipcc all 256 are hoisted and spilled)
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[m][q][r]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[m][4 + q][r]));
+                        o0[q] = x0; o1[q] = x1;
+                    }
+                    const int trow = 32 * (2 * wave + m) + (r & 3) + 8 * (r >> 2);
+                    char *rowp = tile_base + (long)trow * V * 4;  // wave-uniform
+                    if (rows_exist[m]) {
+                        __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
+                        if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
+                    }
+                    float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
+                    if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                    const float M = half_max_dpp(m8, half);
+                    const float nm2 = -M * RNNT_LOG2E;
+                    float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                              (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                    if (BOTH)
+                        e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                             (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                    const float S_ = half_sum_dpp(e, half);
+                    if (i == 31) {
+                        float *sp = s_part + (trow + 4 * half) * 2;
+                        const float m_o = sp[0], s_o = sp[1];
+                        const float mn = fmaxf(m_o, M);
+                        sp[0] = mn;
+                        sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+          };
+          if (cw + 128 < V) epilogue(X3Int<1>{});
+          else epilogue(X3Int<0>{});
+        };
+        run_pass(X3Int<1>{}, 0);
+        for (int pass = 1; pass < npass; ++pass) run_pass(X3Int<0>{}, pass);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        s_den[tid] = s_part[tid * 2] + __logf(s_part[tid * 2 + 1]);
+        __syncthreads();
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int row = tid;
+            const long cell = row0 + row;
+            if (cell < cells) {
+                const int u = (int)(cell % U1);
+                const long bt = cell / U1;
+                const int t = (int)(bt % T), b = (int)(bt / T);
+                const int Ub = len_u(a.target_lens, b, U1);
+                if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
+                    const float den = s_den[row];
+                    const float *lrow = a.logits + cell * V;
+                    const long si = skew_index(b, t, u, a.D, U1);
+                    if (which == 0) {
+                        const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.denom_s[si] = den;
+                        a.lpb_s[si] = lb - den;
+                    } else {
+                        float le = 0.f;
+                        if (u < Ub) {
+                            const int y = a.targets[(long)b * (U1 - 1) + u];
+                            le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                        }
+                        a.lpe_s[si] = le;
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+}
+
+void launch_joint_fwd_x3z(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = XD_NSLOT * XD_WSLOT + 256 * 4 + 256 * 2 * 4 + 16;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_joint_fwd_x3z, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const long cells = (long)a.B * a.T * a.U1;
+    const int ntiles = (int)((cells + 255) / 256);
+    launch_fill32(a.counter, 0u, 4, st);
+    const int nwg = ntiles < a.n_cu ? ntiles : a.n_cu;  // one workgroup per CU (512 registers per wave)
+    hipLaunchKernelGGL(k_joint_fwd_x3z, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+}
+
+// ---------------------------------------------------------------------------------------
 // W for the dHidden product, fragment order, three planes:
 //   [hp (512-column pass)][c (16-deep k-step = 16 vocabulary rows)][plane][tile(16)][lane] x 8 bf16,
 //   element j = piece_plane(W[v = 16c + 8*(lane>>5) + j][h = 512hp + 128*(tile>>2) + 4*(lane&31) + (tile&3)])

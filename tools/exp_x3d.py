@@ -25,7 +25,7 @@ def measure(cfg):
 
     run(255, 0)
     out = []
-    for name, var in (("nw8", engine.VARIANT_X3_FWD_8W), ("nw4", engine.VARIANT_X3_FWD_2WG), ("v1", 0)):
+    for name, var in (("z", engine.VARIANT_X3_FWD_Z), ("nw4", engine.VARIANT_X3_FWD_2WG), ("v1", 0)):
         ts = []
         for _ in range(5):
             run(2, var)
