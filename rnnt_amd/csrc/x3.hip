@@ -30,6 +30,20 @@
 #define X3_EXP 0
 #endif
 #define X3_OFF(bit) ((X3_EXP) & (bit))
+// Diagnostic build only (-DRNNT_STAMPS): workgroup 0 stamps the core clock counter and the 100 MHz reference at its start and
+// end into debug[SLOT..] (a buffer nothing else reads): the clock this launch ran at (tools/exp_x3_clock.py).
+#ifdef RNNT_STAMPS
+#define X3_CLOCK_STAMP(SLOT)                                                                                               \
+    do {                                                                                                                   \
+        if (a.debug && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {                        \
+            unsigned long long t_, r_;                                                                                     \
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");      \
+            a.debug[SLOT] = t_; a.debug[(SLOT) + 1] = r_;                                                                  \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define X3_CLOCK_STAMP(SLOT) do {} while (0)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
     const int B = a.B;
     const long nlive = tab[2 * B + 1];
     const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+    X3_CLOCK_STAMP(128 + 104);
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
                                                           (int)(XW_ROWS * rstride[p]), 0x00020000);
             auto dma_piece = [&](auto n_c) {  // piece n of stage ks+2 -> ring stage DST: plane n>>2, rows 4(n&3)..
                 constexpr int n = decltype(n_c)::value, p = n >> 2, i = n & 3;
-                if (RNNT_XP(a.flags, 8192) || X3_OFF(8)) return;
+                if (RNNT_XP(a.flags, 8192) || X3_OFF(8) || (X3_OFF(8388608) && wave >= 2) || (X3_OFF(33554432) && p == 2)) return;  // 8388608: no hidden stream
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + wave * XW_TILE + DST * XW_STAGE + p * XW_PLANE + 1024 * i),
                                                          16, soff[p][i], 0, 0, 0);
             };
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
             // 16 MFMAs of one product with DMA pieces N0, N0+1 threaded through them
             auto product = [&](const X3Frag &fa_, const X3Frag &fb_, auto n0_c) {
                 constexpr int N0 = decltype(n0_c)::value;
+                constexpr bool DROP = X3_OFF(16777216) && (N0 == 4 || N0 == 8 || N0 == 10);  // what-if: 3 of the 6 products
                 u32x4 fa[4], fb[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
                 }
 #pragma unroll
                 for (int qm = 0; qm < 4; ++qm) {
-                    if (!RNNT_XP(a.flags, 1024)) {
+                    if (!RNNT_XP(a.flags, 1024) && !DROP) {
 #pragma unroll
                         for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x3_mfma(fa[qm], fb[qn], acc[qm][qn]);
                     }
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x3(X3Args a)
         }
     }
 
+    X3_CLOCK_STAMP(128 + 106);
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r of tile
     // (qm,qn): v = v0 + 32qm + (r&3) + 8(r>>2) + 4half, h = h0 + 32qn + (lane&31).
     const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
@@ -962,11 +979,11 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
             }
         };
         auto hid_store = [&](const Prod &P, int kcs) {
-            if (!X3_OFF(128)) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; hdst[2 * kcs + 2 * ps] = P.pl; }
+            if (!X3_OFF(128)) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; if (!X3_OFF(33554432)) hdst[2 * kcs + 2 * ps] = P.pl; }
         };
         // piece n (0..11) of this wave's share of W k-step cs -> ring slot cs & 1
         auto wdma = [&](int cs, int n) {  // raw-buffer form: scalar base and offsets, one constant per-lane offset register
-            if (X3_OFF(8)) return;
+            if (X3_OFF(8) || (X3_OFF(33554432) && n >= 8)) return;  // 33554432: what-if, two planes' worth of bytes
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fw + (cs & 1) * XF_WSLOT + (wave * 12 + n) * 1024), 16, wvo,
                                                      (cs * 48 + wave * 12 + n) * 1024, 0, 0);
         };
@@ -1058,9 +1075,10 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x3(X3Args a, const int nti
                          :: "memory");
             auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto pb_c) {
                 constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value, PB = decltype(pb_c)::value;
+                const bool drop = X3_OFF(16777216) && (PA == 2 || (PA == 1 && &bcur[0] == &bn[0]) || (PA == 0 && NB < 0 && PB < 0));  // what-if: 3 of the 6 products
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if (!X3_OFF(1)) {
+                    if (!X3_OFF(1) && !drop) {
                         acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
                         acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
                     }
@@ -2004,6 +2022,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub);
     const int t0 = tt * XG_BT, u0 = ub * XG_BU;
     const int VC = V / 16;
+    if (FIRST) X3_CLOCK_STAMP(128 + 108);  // (one tile of ~0.1 ms: 1e-4 resolution at the 100 MHz reference)
 
     // ---- producer role: M tile `wave`, row i = cell (pt, pu)
     const int prow = wave * 32 + i;
@@ -2173,7 +2192,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
     };
     auto wdma = [&](int c, int n) {  // piece n (0..11) of this wave's share of W k-step c -> ring slot c & 1
         const int cc = c < VC ? c : VC - 1;
-        if (X3_OFF(8)) return;
+        if (X3_OFF(8) || (X3_OFF(33554432) && n >= 8)) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + (c & 1) * XG_WSLOT + (wave * 12 + n) * 1024), 16, wvo,
                                                  (cc * 48 + wave * 12 + n) * 1024, 0, 0);
     };
@@ -2253,9 +2272,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             auto block = [&](auto pa_c, const u32x4 (&bcur)[8], u32x4 (&bnext)[8], auto nb_c, auto d0_c, auto s0_c, auto mem_c) {
                 constexpr int PA = decltype(pa_c)::value, NB = decltype(nb_c)::value, D0 = decltype(d0_c)::value, S0 = decltype(s0_c)::value;
                 constexpr int MEM = decltype(mem_c)::value;
+                constexpr bool DROP = X3_OFF(16777216) && (PA == 2 || MEM == 2 || MEM == 3);  // what-if: 3 of the 6 products
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    if (!X3_OFF(1)) {
+                    if (!X3_OFF(1) && !DROP) {
                         acc[0][q] = x3_mfma(af[0][PA], bcur[q], acc[0][q]);
                         acc[1][q] = x3_mfma(af[1][PA], bcur[q], acc[1][q]);
                     }
@@ -2428,6 +2448,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x3(X3Args a, const int hp)
             }
         }
     }
+    if (FIRST) X3_CLOCK_STAMP(128 + 110);
 }
 
 bool x3_dhidden_ok(int U1, int H, int V)
