@@ -54,6 +54,14 @@ extern "C" {
  * Measured error against fp64 is below the fp32 MFMA route's (tools/bf16x3_accuracy.py, tests).  Fused
  * entry only; needs H % 128 == 0, V % 128 == 0 (the Python host side zero-pads other shapes). */
 #define RNNT_DTYPE_F32_BF16X3 2
+/* fp32-CLASS arithmetic on the fp16 matrix pipes at HALF the matrix work of RNNT_DTYPE_F32_BF16X3 ("f16x2", round 4): the
+ * three bf16x3 GEMM kernels turned out power-bound (the chip holds 1.7-2.1 GHz under their MFMA stream), so the remaining
+ * lever is fewer products.  Every operand of the three GEMMs is scaled by a power of two into fp16's range and split into
+ * TWO fp16 pieces (hi + mid = the value to 2^-22: 11 + 11 significant bits); a product is the sum of THREE fp16 MFMA
+ * products (hi.hi + hi.mid + mid.hi, fp32 accumulation) — rnnt_amd/csrc/x2.hip.  Same boundary, same 1e-4 parity bar, same
+ * stages, variants and workspace objects as the bf16x3 route (no third plane); measured error against fp64: tests/test_x2_gpu.py.
+ * Fused entry only; needs H % 128 == 0, V % 128 == 0. */
+#define RNNT_DTYPE_F32_F16X2 3
 
 #define RNNT_OK 0
 #define RNNT_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim, bad blank ...        */

@@ -49,9 +49,9 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
 {
-    if (dtype != RNNT_DTYPE_F32 && dtype != RNNT_DTYPE_BF16 && dtype != RNNT_DTYPE_F32_BF16X3)
-        return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (RNNT_DTYPE_F32 / RNNT_DTYPE_BF16 / RNNT_DTYPE_F32_BF16X3)", dtype);
-    const char *dname = dtype == RNNT_DTYPE_BF16 ? "RNNT_DTYPE_BF16" : "RNNT_DTYPE_F32_BF16X3";
+    if (dtype != RNNT_DTYPE_F32 && dtype != RNNT_DTYPE_BF16 && dtype != RNNT_DTYPE_F32_BF16X3 && dtype != RNNT_DTYPE_F32_F16X2)
+        return fail(RNNT_ERR_UNSUPPORTED, "dtype %d not supported (RNNT_DTYPE_F32 / RNNT_DTYPE_BF16 / RNNT_DTYPE_F32_BF16X3 / RNNT_DTYPE_F32_F16X2)", dtype);
+    const char *dname = dtype == RNNT_DTYPE_BF16 ? "RNNT_DTYPE_BF16" : dtype == RNNT_DTYPE_F32_F16X2 ? "RNNT_DTYPE_F32_F16X2" : "RNNT_DTYPE_F32_BF16X3";
     if (dtype != RNNT_DTYPE_F32 && !need_h)
         return fail(RNNT_ERR_UNSUPPORTED, "%s only applies to the fused joint+loss entry", dname);
     if (dtype != RNNT_DTYPE_F32 && (H <= 0 || H % 128 != 0 || V <= 0 || V % 128 != 0))
@@ -81,7 +81,8 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
 {
     const size_t D = (size_t)T + U1 - 1;
     const size_t cells = (size_t)B * T * U1, skew = (size_t)B * D * U1;
-    const bool bf = dtype == RNNT_DTYPE_BF16, x3 = dtype == RNNT_DTYPE_F32_BF16X3;
+    const bool bf = dtype == RNNT_DTYPE_BF16, x2 = dtype == RNNT_DTYPE_F32_F16X2, x3 = dtype == RNNT_DTYPE_F32_BF16X3 || x2;
+    // (x3: the split-operand routes — bf16x3, and f16x2 with two planes instead of three)
     // G / hidden rows are padded with >= 1 zero row up to a multiple of 16 (dW chunk size)
     // (bf16 / bf16x3 routes: multiple of 32 = one granule of their live-row table)
     const size_t rows_pad = (bf || x3) ? (cells + 1 + 31) / 32 * 32 : (cells + 1 + 15) / 16 * 16;
@@ -101,8 +102,8 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     } else if (x3) {
         const size_t ra = (size_t)bf16_rows_alloc(rows_pad);
         L->logits = o;   o += align_up(ra * V * 4);      // fp32 logits; G hi | mid planes in place
-        L->hidden = o;   o += align_up(3 * ra * H * 2);  // three bf16 planes
-        L->g_lo = o;     o += align_up(ra * V * 2);      // lo plane of G
+        L->hidden = o;   o += align_up((x2 ? 2 : 3) * ra * H * 2);  // three bf16 planes (f16x2: two fp16 planes)
+        L->g_lo = o;     if (!x2) o += align_up(ra * V * 2);      // lo plane of G (f16x2: none)
     } else {
         L->logits = o;   o += align_up((rows_pad + 16) * V * 4);
         L->hidden = o;   o += align_up((rows_pad + 16) * H * 4);
@@ -115,6 +116,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     L->coef = o;     o += align_up(cells * 16);
     L->wpack = o;
     if (bf) o += align_up(bf16_wpack_fwd_bytes(H, V)) + align_up(bf16_wpack_dh_bytes(H, V));
+    else if (x2) o += align_up(x2_wpack_fwd_bytes(H, V)) + align_up(x2_wpack_dh_bytes(H, V));
     else if (x3) o += align_up(x3_wpack_fwd_bytes(H, V)) + align_up(x3_wpack_dh_bytes(H, V));
     else o += align_up(wpack_floats(H, V) * 4);
     L->enc_copy = o; o += align_up((size_t)B * T * H * 4);
@@ -272,7 +274,9 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     g.n_ublk = L.n_ublk; g.n_ttile = L.n_ttile; g.n_split = L.n_split;
     g.counter = (unsigned *)(ws + L.counters); g.dw_tab = (long *)(ws + L.counters + 1024); g.n_cu = device_cus(); g.flags = xflags & ~16; g.debug = g_debug; g.pred_split_col = 0;
     g.gen_bu = dtype == RNNT_DTYPE_BF16 ? 16 : dhidden_gen_bu(T, U1);  // u width of the dHidden tiles
-    if (dtype == RNNT_DTYPE_F32_BF16X3) {
+    if (dtype == RNNT_DTYPE_F32_BF16X3 || dtype == RNNT_DTYPE_F32_F16X2) {
+        // RNNT_DTYPE_F32_F16X2 (x2.hip): the same stages on two fp16 planes and three products; operand scales below
+        const bool x2 = dtype == RNNT_DTYPE_F32_F16X2;
         // fp32-accurate route on the bf16 matrix pipes (x3.hip).  Stage by stage the fp32 route's own kernel can
         // stand in (RNNT_VARIANT_X3_FP32_FWD / _DH): same data, one stage swapped — how each x3 kernel is checked.
         X3Args h;
@@ -280,7 +284,14 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.W = (const float *)W; h.bias = (const float *)bias;
         h.rows_pad = (long)L.rows_pad; h.rows_alloc = bf16_rows_alloc(L.rows_pad);
         h.hidden = (unsigned short *)(ws + L.hidden); h.plane_stride = h.rows_alloc * (long)H;
-        h.wpack_fwd = ws + L.wpack; h.wpack_dh = ws + L.wpack + align_up(x3_wpack_fwd_bytes(H, V));
+        h.wpack_fwd = ws + L.wpack; h.wpack_dh = ws + L.wpack + align_up(x2 ? x2_wpack_fwd_bytes(H, V) : x3_wpack_fwd_bytes(H, V));
+        {   // f16x2 operand scales: |G| <= grad_scale <= 2^e -> g_scale = 2^(13 - e); hidden: 2^14 (x2.hip)
+            int e = 0;
+            (void)frexpf(grad_scale, &e);
+            h.g_scale = ldexpf(1.0f, 13 - e);
+            h.dw_rescale = 1.0f / (h.g_scale * 16384.0f); h.db_rescale = 1.0f / h.g_scale;
+            h.scales = (const float *)(ws + L.counters + 640);
+        }
         h.logits = logits; h.g_lo = (unsigned short *)(ws + L.g_lo); h.coef = coef;
         h.targets = targets; h.logit_lens = logit_lens; h.target_lens = target_lens;
         h.denom_s = denom_s; h.lpb_s = lpb_s; h.lpe_s = lpe_s; h.D = L.D;
@@ -289,8 +300,8 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         h.n_ublk = L.n_ublk; h.n_split = L.n_split; h.flags = xflags; h.n_ublk16 = (U1 + 15) / 16;
         h.dw_tab = (long *)(ws + L.counters + 1024);
         h.counter = (unsigned *)(ws + L.counters + 512); h.n_cu = device_cus(); h.debug = g_debug;
-        const bool f32_dh = (xflags & RNNT_VARIANT_X3_FP32_DH) != 0 || !x3_dhidden_ok(U1, H, V);
-        const bool f32_fwd = (xflags & RNNT_VARIANT_X3_FP32_FWD) != 0 || !x3_fwd_ok(U1, H, V) || f32_dh;  // fp32 dHidden reads fp32 hidden
+        const bool f32_dh = (xflags & RNNT_VARIANT_X3_FP32_DH) != 0 || !(x2 ? x2_dhidden_ok(U1, H, V) : x3_dhidden_ok(U1, H, V));
+        const bool f32_fwd = (xflags & RNNT_VARIANT_X3_FP32_FWD) != 0 || !(x2 ? x2_fwd_ok(U1, H, V) : x3_fwd_ok(U1, H, V)) || f32_dh;  // fp32 dHidden reads fp32 hidden
         if ((f32_fwd || f32_dh) && ws_bytes < L.total + L.aux_bytes)
             return fail(RNNT_ERR_WORKSPACE, "workspace %zu < %zu bytes: a stage on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*, or a "
                         "shape k_joint_fwd_x3 / k_dhidden_x3 do not cover) needs total + aux_bytes of rnnt_engine_workspace_layout",
@@ -305,8 +316,8 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
             g.gen_bu = 16; g.pred_split_col = H;  // x3 tiles: 8 t x 16 u, every dPred slab 8 t rows high
         }
         if (stages & ST_PROD) {
-            launch_x3_zero_padding(h, 1, st);
-            launch_x3_pack_w(h, st);
+            if (x2) { launch_x2_zero_padding(h, 1, st); launch_x2_pack_w(h, (float *)(ws + L.counters + 640), st); }
+            else { launch_x3_zero_padding(h, 1, st); launch_x3_pack_w(h, st); }
             if (f32_fwd) {
                 const size_t cells = (size_t)B * T * U1;
                 launch_fill32(hid32 + cells * H, 0u, (L.rows_pad + 16 - cells) * H * 4, st);
@@ -324,7 +335,10 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
                 f.B = B; f.T = T; f.U1 = U1; f.H = H; f.V = V; f.D = L.D; f.blank = blank; f.flags = 0; f.debug = nullptr;
                 f.make_hidden = 1; f.counter = h.counter; f.n_cu = h.n_cu;
                 launch_joint_fwd(f, st);
-                launch_x3_make_hidden(h, st);  // the planes the backward reads
+                if (x2) launch_x2_make_hidden(h, st);
+                else launch_x3_make_hidden(h, st);  // the planes the backward reads
+            } else if (x2) {
+                launch_joint_fwd_x2(h, st);
             } else if ((xflags & (RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z)) && x3_fwd_d_ok(U1, H, V)) {
                 launch_joint_fwd_x3d(h, (xflags & RNNT_VARIANT_X3_FWD_8W) ? 8 : 4, st);
             } else {
@@ -338,22 +352,27 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
             launch_coef(alpha_s, beta_s, denom_s, lpb_s, lpe_s, targets, logit_lens, target_lens, coef,
                         B, T, U1, L.D, grad_scale, st);
         if (stages & ST_DH) {
-            launch_x3_zero_padding(h, 2, st);
+            if (x2) launch_x2_zero_padding(h, 2, st);
+            else launch_x3_zero_padding(h, 2, st);
             if (f32_dh) {
                 if (!fuse_g32) launch_make_g(g, st);
                 launch_dhidden(g, st);     // leaves fp32 G in place of the logits
-                launch_x3_split_g(h, st);  // -> hi | mid in place, lo beside
+                if (x2) launch_x2_split_g(h, st);
+                else launch_x3_split_g(h, st);  // -> hi | mid in place, lo beside
+            } else if (x2) {
+                launch_dhidden_x2(h, st);
             } else {
                 launch_dhidden_x3(h, st);
             }
         }
         if (stages & ST_DH_RED) launch_dhidden_reduce(g, st);
         if (stages & ST_DW) {
-            if (xflags & RNNT_VARIANT_X3_DW_P16) launch_dw_x3p(h, st);
+            if (x2) launch_dw_x2(h, st);
+            else if (xflags & RNNT_VARIANT_X3_DW_P16) launch_dw_x3p(h, st);
             else launch_dw_x3(h, st);
         }
         if (stages & ST_DW_RED) launch_dw_reduce(g, st);
-        return launch_status("rnnt_engine fused pipeline (bf16x3)");
+        return launch_status(x2 ? "rnnt_engine fused pipeline (f16x2)" : "rnnt_engine fused pipeline (bf16x3)");
     }
     if (dtype == RNNT_DTYPE_BF16) {
         Bf16Args h;

@@ -149,6 +149,10 @@ struct X3Args {
     unsigned *counter;   // zeroable word: tile counter of the persistent forward
     int n_cu;
     unsigned long long *debug;  // diagnostic stamp buffer (RNNT_STAMPS builds), else NULL
+    // RNNT_DTYPE_F32_F16X2 (x2.hip; `hidden` then holds two fp16 planes, G two fp16 planes in place of the logits, no g_lo):
+    float g_scale;              // power of two with |g_scale G| <= 2^13 (from grad_scale)
+    float dw_rescale, db_rescale;  // 1 / (g_scale 2^14), 1 / g_scale
+    const float *scales;        // device: {s_W, 1 / s_W} (k_x2_wscale, every call)
 };
 bool x3_fwd_ok(int U1, int H, int V);      // the bf16x3 forward kernel covers this shape (else: the fp32 route's)
 bool x3_dhidden_ok(int U1, int H, int V);  // likewise k_dhidden_x3
@@ -164,7 +168,19 @@ void launch_joint_fwd_x3z(const X3Args &a, hipStream_t st);  // one wave per SIM
 void launch_joint_fwd_x3d(const X3Args &a, int nw, hipStream_t st);  // two waves per SIMD, A in registers (RNNT_VARIANT_X3_FWD_2WG / _8W)
 void launch_dhidden_x3(const X3Args &a, hipStream_t st);
 void launch_dw_x3(const X3Args &a, hipStream_t st);   // v_mfma_f32_32x32x16_bf16, six products per k-step (default)
-void launch_dw_x3p(const X3Args &a, hipStream_t st);  // v_mfma_f32_16x16x32_bf16, two products per MFMA (RNNT_VARIANT_X3_DW_P16)
+void launch_dw_x3p(const X3Args &a, hipStream_t st);
+// RNNT_DTYPE_F32_F16X2 (x2.hip): the bf16x3 route's stages on two fp16 planes and three products
+bool x2_fwd_ok(int U1, int H, int V);
+bool x2_dhidden_ok(int U1, int H, int V);
+size_t x2_wpack_fwd_bytes(int H, int V);
+size_t x2_wpack_dh_bytes(int H, int V);
+void launch_x2_make_hidden(const X3Args &a, hipStream_t st);
+void launch_x2_split_g(const X3Args &a, hipStream_t st);
+void launch_x2_zero_padding(const X3Args &a, int what, hipStream_t st);
+void launch_x2_pack_w(const X3Args &a, float *scales, hipStream_t st);  // s_W from max |W|, then both packs
+void launch_joint_fwd_x2(const X3Args &a, hipStream_t st);
+void launch_dhidden_x2(const X3Args &a, hipStream_t st);
+void launch_dw_x2(const X3Args &a, hipStream_t st);  // v_mfma_f32_16x16x32_bf16, two products per MFMA (RNNT_VARIANT_X3_DW_P16)
 
 // ---- decode.hip
 void launch_scan_logits(const float *enc, long enc_st, const float *pred, const float *W, const float *bias,

@@ -20,9 +20,11 @@ LIB_PATH = os.environ.get("RNNT_ENGINE_LIB") or os.path.join(_CSRC, "librnnt_eng
 DTYPE_F32 = 0
 DTYPE_BF16 = 1  # bf16 GEMM operands, fp32 accumulate, fp16 logits (workspace), fp32/fp64 loss; fp32 tensors at the boundary
 DTYPE_F32_BF16X3 = 2  # fp32-accurate products as six bf16 MFMA products of 3-way split operands (x3.hip)
+DTYPE_F32_F16X2 = 3  # fp32-class products as three fp16 MFMA products of scaled, 2-way split operands (x2.hip): half the bf16x3 route's matrix work
 _DTYPES = {"fp32": DTYPE_F32, "f32": DTYPE_F32, "float32": DTYPE_F32, DTYPE_F32: DTYPE_F32,
            "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, DTYPE_BF16: DTYPE_BF16,
-           "bf16x3": DTYPE_F32_BF16X3, "f32_bf16x3": DTYPE_F32_BF16X3, DTYPE_F32_BF16X3: DTYPE_F32_BF16X3}
+           "bf16x3": DTYPE_F32_BF16X3, "f32_bf16x3": DTYPE_F32_BF16X3, DTYPE_F32_BF16X3: DTYPE_F32_BF16X3,
+           "f16x2": DTYPE_F32_F16X2, "f32_f16x2": DTYPE_F32_F16X2, DTYPE_F32_F16X2: DTYPE_F32_F16X2}
 
 
 class _Int32:
@@ -87,7 +89,7 @@ def dtype_code(dtype):
     try:
         return _DTYPES[dtype]
     except (KeyError, TypeError):
-        raise ValueError(f"rnnt_amd: unsupported compute dtype {dtype!r} (fp32, bf16 or bf16x3)") from None
+        raise ValueError(f"rnnt_amd: unsupported compute dtype {dtype!r} (fp32, bf16, bf16x3 or f16x2)") from None
 _lock = threading.Lock()
 _lib = None
 _workspaces = {}

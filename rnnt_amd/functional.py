@@ -220,7 +220,7 @@ def joint_rnnt_loss(enc, pred, W, bias, targets, logit_lengths, target_lengths, 
     if code == engine.DTYPE_BF16:  # no host-side padding on this route: the C side validates
         enc_p, pred_p, W_p, bias_p = enc, pred, W, bias
     else:
-        enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias, 128 if code == engine.DTYPE_F32_BF16X3 else 4)
+        enc_p, pred_p, W_p, bias_p, H, V = _pad_hv(enc, pred, W, bias, 128 if code in (engine.DTYPE_F32_BF16X3, engine.DTYPE_F32_F16X2) else 4)
     scale = float(grad_scale) if grad_scale is not None else (1.0 / B if reduction == "mean" else 1.0)
     # validation / eval (reference rnnt/train.py:170-201 runs the model under no_grad): costs only
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (enc, pred, W, bias))
