@@ -460,14 +460,425 @@ void launch_dw_x2(const X3Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_dw_x2, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
 }
 
-// (to come: the fused forward and dHidden kernels; until then those stages run on the fp32 route's kernels + the plain producers)
-bool x2_fwd_ok(int, int, int) { return false; }
-bool x2_dhidden_ok(int, int, int) { return false; }
-size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H / 16) * 2 * 16 * 64 * 16; }
+#define XG2_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
+#define XG2_WAIT8_BUT(b, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")
+
+// ---------------------------------------------------------------------------------------
+// W (scaled by s_W) for the dHidden product, fragment order, two planes:
+//   [hp (512-column pass)][c (16-deep k-step = 16 vocabulary rows)][plane][tile(16)][lane] x 8 fp16,
+//   element j = piece_plane(s_W W[v = 16c + 8*(lane>>5) + j][h = 512hp + 128*(tile>>2) + 4*(lane&31) + (tile&3)])
+// (columns interleaved by 4: a lane's 4 tiles of a 128-column group are 4 adjacent columns -> 16-byte epilogue accesses).
+// One k-step = 2 x 16 KiB, staged by one linear LDS-DMA copy.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_x2_pack_w_dh(const float *__restrict__ W, const float *__restrict__ scales, u32x4 *__restrict__ out, int H, int V, long n)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (hp, c, tile, lane): one thread writes both planes
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 15;
+    const int VC = V / 16;
+    const int c = (int)((idx >> 10) % VC), hp = (int)((idx >> 10) / VC);
+    const int h = 512 * hp + 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
+    const int v0 = 16 * c + 8 * (lane >> 5);
+    const float sw = scales[0];
+    u32x4 ph = {0u, 0u, 0u, 0u}, pm = ph;
+    if (h < H) {
+        const float *w = W + (long)v0 * H + h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const X2Pieces q = x2_split2(x2_clamp(w[(long)(2 * j) * H] * sw), x2_clamp(w[(long)(2 * j + 1) * H] * sw));
+            ph[j] = q.h; pm[j] = q.m;
+        }
+    }
+    u32x4 *o = out + ((long)hp * VC + c) * 2048 + tile * 64 + lane;
+    o[0] = ph; o[1024] = pm;
+}
 size_t x2_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V / 16) * 2 * 16 * 64 * 16; }
+
+// ---------------------------------------------------------------------------------------
+// k_dhidden_x2: k_dhidden_x3 on two planes.  G from the fp32 logits (exp2 + the two occupancy corrections, as the fp32 route),
+// scaled by g_scale, split into its two fp16 planes, stored in place (hi | mid over each 32-wide chunk of the logits row: the
+// planes fill exactly the bytes of the logits they replace) and multiplied: dHidden = G . W over 512 columns of H per launch;
+// epilogue as the fp32 kernel: x (1 - hidden^2), sum over u -> dEnc slab, sum over t -> dPred slab.  Tile = 8 t x 16 u cells.
+// 4 waves = 2 (M) x 2 (N), wave tile 64 cells x 256 columns = 16 accumulator tiles (256 registers).
+//  * production: wave w turns M tile w (32 cells) into G: lane (cell i = l&31, half) owns the 8 vocabulary entries 16c +
+//    8*half .. +7 of its cell per k-step — its slot of the MFMA A fragment — and drops 16 bytes per plane into the LDS exchange
+//    [2 slots][M tile][plane][lane]; logits requested 4 k-steps ahead (register ring);
+//  * G leaves in WHOLE 128-byte lines (32 x hi | 32 x mid of one cell and chunk = the fragments of two k-steps x two halves x
+//    two planes), read back by the producing wave from its part of the exchange every second k-step: 4 store instructions;
+//  * W: one linear LDS-DMA copy of 32 KiB per k-step into a 2-slot ring (8 DMAs per wave);
+//  * per k-step ONE barrier publishes W slot c and exchange slot c; then 3 products x 16 MFMAs:
+//      block 0  ah.bh   + the 8 fragment reads of W's mid plane + production slices 0-7 of G(c+1) (exp2, corrections, split)
+//      block 1  am.bh   + exchange write of G(c+1), W DMAs 0-6 of k-step c+1, (even c) the pair's line reads
+//      block 2  ah.bm   + W DMA 7, (even c) the 4 line stores, the 2 raw logits loads of k-step c+5
+//    (memory operations in ONE fixed order per k-step — DMAs, then stores, then loads — so that every vmcnt is a count).
+// FIRST = false (H > 512: columns 512.., one launch per further 512): G's planes are read back from memory into the exchange
+// instead of being produced; nothing is stored but the slabs.
+// The accumulators hold g_scale s_W dHidden: the epilogue's sums are multiplied by 1 / (g_scale s_W) (a power of two).
+// grid (n_ublk, ceil(T/8), B).  Requires V % 128 == 0, H % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define XG2_BT 8
+#define XG2_BU 16
+#define XG2_WSLOT 32768   // one k-step of W: 2 planes x 16 tiles x 1 KiB
+#define XG2_XSLOT 8192    // one k-step of G fragments: 4 M tiles x 2 planes x 1 KiB
+template <bool FIRST>
+__global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
+{
+    // [0, 64 KiB): W ring, 2 slots;  [64, 80 KiB): G exchange, 2 slots.  The epilogue reuses the W ring.
+    extern __shared__ __attribute__((aligned(1024))) char s_dh[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int T = a.T, U1 = a.U1, H = a.H, V = a.V;
+    const int ub = blockIdx.x, tt = blockIdx.y, b = blockIdx.z;
+    int Tb, Ub;
+    len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub);
+    const int t0 = tt * XG2_BT, u0 = ub * XG2_BU;
+    const int VC = V / 16;
+
+    // ---- producer role: M tile `wave`, row i = cell (pt, pu)
+    const int prow = wave * 32 + i;
+    const int pt = t0 + (prow >> 4), pu = u0 + (prow & 15);
+    const bool pexists = pt < T && pu < U1;
+    const long zrow = (long)a.B * T * U1;  // first zero padding row
+    const long pcell = pexists ? ((long)b * T + pt) * U1 + pu : zrow;
+
+    // workgroup-uniform: no products past the utterance's length or in a u block past U_b (no lattice cell; the reductions
+    // skip its slabs), but k_dw_x2 must find zeros in these rows (both planes = the whole logits row)
+    if (t0 >= Tb || u0 > Ub) {
+        if (FIRST && pexists) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            u32x4 *g = (u32x4 *)(a.logits + pcell * V) + half;
+            for (int c = 0; c < VC; ++c) {  // this lane's 16 B of each plane per k-step (layout below)
+                g[8 * (c >> 1) + 2 * (c & 1)] = z;
+                g[8 * (c >> 1) + 4 + 2 * (c & 1)] = z;
+            }
+        }
+        return;
+    }
+
+    CellCoef cf = a.coef[pexists ? pcell : 0];
+    const bool live = pexists && pt < Tb && cf.c1 != RNNT_NEG_INF;
+    if (!live) { cf.c1 = RNNT_NEG_INF; cf.sb = 0.f; cf.se = 0.f; cf.y = -1; }
+    const float gs = a.g_scale;
+    // The producer's memory, per k-step c (16 vocabulary entries, this lane: 8 of them, v = 16c + 8half + j):
+    //   logits (fp32): 32 bytes at row + 64c + 32half               (f32x4 index 4c + 2half, +1)
+    //   G hi: 16 bytes at row + 128(c>>1) + 32(c&1) + 16half        (u32x4 index 8(c>>1) + 2(c&1) + half);  G mid: + 64 bytes
+    // rows outside the lattice read the zero padding row (finite) with c1 = -inf -> G = 0; FIRST = false: every existing row
+    // holds its G planes already
+    const float *xsrc = a.logits + ((FIRST ? live : pexists) ? pcell : zrow) * V;
+    const int blank = a.blank;
+    // whole-line stores (k_dhidden_x3, round 4): lane L -> row 8n + (L >> 3) of the M tile (n = 0..3: four store instructions,
+    // 8 whole lines each), piece L & 7 = (plane, k-step parity, half), read back from this wave's part of the exchange (both
+    // slots hold the pair between the exchange write of the odd k-step and the next even one's).  Raw-buffer stores over the
+    // tile's rows: rows outside the lattice get an offset past the range (dropped): every wave issues the same instructions.
+    const int lds0 = (int)(size_t)(lds_vptr)s_dh;
+    const int lpiece = lane & 7, lrow = lane >> 3;
+    // LDS: [slot = parity][M tile wave][plane][lane slot = row + 32 half]
+    const int xl = lds0 + 2 * XG2_WSLOT + ((lpiece >> 1) & 1) * XG2_XSLOT + wave * 2048 + (lpiece >> 2) * 1024 + 16 * (lrow + 32 * (lpiece & 1));
+    const long tile_cell0 = ((long)b * T + t0) * U1 + u0;  // the tile's first cell (exists: t0 < Tb <= T, u0 <= Ub < U1)
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.logits + tile_cell0 * V), 0, (int)((((long)(XG2_BT - 1) * U1 + XG2_BU) * V) * 4), 0x00020000);
+    int lvo[4];  // byte offset of this lane's piece of line n in the buffer: row (t0 + 2 wave + (n >> 1), u0 + 8 (n & 1) + lrow)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int lt = 2 * wave + (n >> 1), lu = 8 * (n & 1) + lrow;
+        const bool ex = t0 + lt < T && u0 + lu < U1;
+        lvo[n] = ex ? (int)(((long)lt * U1 + lu) * V * 4) + 64 * (lpiece >> 2) + 16 * (lpiece & 3) : 0x7ffffff0;
+    }
+
+    f32x16 acc[2][8];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+
+    const int xw = lds0 + 2 * XG2_WSLOT + wave * 2048 + 16 * lane;       // exchange write: [slot][M tile wave][plane][lane]
+    const int xa = lds0 + 2 * XG2_WSLOT + (2 * wm) * 2048 + 16 * lane;   // exchange read: M tiles 2wm, 2wm+1
+    const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                   // W read: tiles 8wn .. 8wn+7 of each plane
+    // W DMA: wave w copies pieces 8w .. 8w+7 of the k-step's 32 (piece = 1 KiB = one (plane, tile)); raw-buffer form: scalar
+    // base (this launch's 512-column pass) and offsets, one constant per-lane offset
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((char *)a.wpack_dh + (long)hp * VC * XG2_WSLOT, 0, VC * XG2_WSLOT, 0x00020000);
+    const int wvo = lane * 16;
+
+    struct Raw { f32x4 x0, x1; };  // FIRST: 8 fp32 logits; else: hi | mid planes (as x0, x1 bits)
+    auto xload = [&](Raw &r, int c, int part = 3) {  // part: 1 first half, 2 second half, 3 both
+        const int cc = c < VC ? c : VC - 1;
+        if (FIRST) {
+            const f32x4 *p = (const f32x4 *)xsrc + 4 * cc + 2 * half;
+            if (part & 1) r.x0 = p[0];
+            if (part & 2) r.x1 = p[1];
+        } else {
+            const u32x4 *p = (const u32x4 *)xsrc + 8 * (cc >> 1) + 2 * (cc & 1) + half;
+            if (part & 1) r.x0 = __builtin_bit_cast(f32x4, p[0]);
+            if (part & 2) r.x1 = __builtin_bit_cast(f32x4, p[4]);
+        }
+    };
+    // G of k-step c from the raw values -> exchange slot (c & 1).  The work is cut into slices (0..8) that the main loop
+    // threads through the gaps of its first MFMA blocks.
+    struct Prod { f32x4 g0, g1; u32x4 ph, pm; };
+    auto produce_slice = [&](Prod &P, const Raw &r, int c, int sl) {
+        if (!FIRST) {
+            if (sl == 0) { P.ph = __builtin_bit_cast(u32x4, r.x0); P.pm = __builtin_bit_cast(u32x4, r.x1); }
+        } else if (sl < 4) {
+            P.g0[sl] = __builtin_amdgcn_exp2f(fmaf(r.x0[sl], RNNT_LOG2E, cf.c1));
+            P.g1[sl] = __builtin_amdgcn_exp2f(fmaf(r.x1[sl], RNNT_LOG2E, cf.c1));
+        } else if (sl == 4) {
+            const int vb = 16 * c + 8 * half;
+            const unsigned dy = (unsigned)(cf.y - vb);
+            if (__any(dy < 8u)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    P.g0[e] = (dy == (unsigned)e) ? P.g0[e] - cf.se : P.g0[e];
+                    P.g1[e] = (dy == (unsigned)(e + 4)) ? P.g1[e] - cf.se : P.g1[e];
+                }
+            }
+        } else if (sl == 5) {
+            const int vb = 16 * c + 8 * half;
+            if ((unsigned)(blank - 16 * c) < 16u) {  // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    P.g0[e] = (vb + e == blank) ? P.g0[e] - cf.sb : P.g0[e];
+                    P.g1[e] = (vb + e + 4 == blank) ? P.g1[e] - cf.sb : P.g1[e];
+                }
+            }
+        } else if (sl == 6) {
+            const f32x4 s4 = P.g0 * gs;  // (|G| <= grad_scale: no clamp needed; exact: a power of two)
+            X2_SPLIT4(s4, P.ph, P.pm, 0);
+        } else if (sl == 7) {
+            const f32x4 s4 = P.g1 * gs;
+            X2_SPLIT4(s4, P.ph, P.pm, 2);
+        }
+        if (sl == 8) {
+            const int dst = xw + (c & 1) * XG2_XSLOT;
+            asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(P.ph) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
+        }
+    };
+    auto produce = [&](const Raw &r, int c) {  // all slices at once (pipeline prologue)
+        Prod P;
+#pragma unroll
+        for (int sl = 0; sl < 9; ++sl) produce_slice(P, r, c, sl);
+    };
+    auto wdma = [&](int c, int n) {  // piece n (0..7) of this wave's share of W k-step c -> ring slot c & 1
+        const int cc = c < VC ? c : VC - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + (c & 1) * XG2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
+                                                 (cc * 32 + wave * 8 + n) * 1024, 0, 0);
+    };
+
+    Raw xr[4];  // raw ring (slot = k-step & 3), 4 k-steps ahead of production
+    xload(xr[0], 0); xload(xr[1], 1); xload(xr[2], 2); xload(xr[3], 3);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) wdma(0, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the in-place stores of the first pair overwrite logits of k-steps 0, 1
+    produce(xr[0], 0);
+    xload(xr[0], 4);
+
+    for (int c0 = 0; c0 < VC; c0 += 4) {  // VC % 4 == 0 (V % 128 == 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            // W k-step c landed (this wave's share), G fragments of step c written: publish both; every wave is past its reads of
+            // step c-1 (W slot and exchange slot of c+1).  vmcnt retires in order: behind the previous k-step's DMAs come its
+            // (even k-step) 4 line stores and its 2 raw loads.  In-place safety: a pair's line overwrites the logits of its own two
+            // k-steps, both loaded — and waited for by this counter — at least two k-steps before the store is issued.
+            if (FIRST && (j & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            x2_lds_barrier();
+            const int ws = wb + (j & 1) * XG2_WSLOT, xs = xa + (j & 1) * XG2_XSLOT;
+            u32x4 af[2][2], bf[8], bn[8];
+            // fragment reads: A (4) and the hi plane of W (8)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 2048 + p * 1024));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                           "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
+                         :: "memory");
+            Prod P;
+            const bool prod_on = c + 1 < VC;  // workgroup-uniform
+            const Raw &rawn = xr[(j + 1) & 3];
+            u32x4 ln[4];  // the pair's lines, 16 bytes per lane each (even k-steps)
+            auto line_read = [&](u32x4 &v, auto n_c) {  // rows 8n .. 8n+7 of the M tile: lane slot + 8n
+                const int xl_ = xl;  // (a local: asm operands cannot name a capture of the enclosing generic lambda)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(xl_), "n"(128 * decltype(n_c)::value));
+            };
+            auto line_store = [&](u32x4 &v, int n, int ce) {  // line n of the pair (ce, ce + 1): chunk ce >> 1 of the rows
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) :: "memory");
+                __builtin_amdgcn_raw_buffer_store_b128(v, grs, lvo[n], 128 * (ce >> 1), 0);
+            };
+            // one product block: 16 MFMAs = (2 M tiles) x (8 column tiles) for A plane PA against the B plane held in `bcur`;
+            // BLK names the work threaded through it (the kernel comment's table)
+            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], auto blk_c) {
+                constexpr int PA = decltype(pa_c)::value, BLK = decltype(blk_c)::value;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc[0][q] = x2_mfma(af[0][PA], bcur[q], acc[0][q]);
+                    acc[1][q] = x2_mfma(af[1][PA], bcur[q], acc[1][q]);
+                    if (BLK == 0) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[q]) : "v"(ws), "n"(16384 + q * 1024));
+                        if (prod_on) produce_slice(P, rawn, c + 1, q);
+                    }
+                    if (BLK == 1) {
+                        if (q == 0 && prod_on) produce_slice(P, rawn, c + 1, 8);
+                        if (q >= 1) wdma(c + 1, q - 1);
+                        if (FIRST && q == 2 && !(j & 1) && prod_on) { line_read(ln[0], X2Int<0>{}); line_read(ln[1], X2Int<1>{}); }
+                        if (FIRST && q == 4 && !(j & 1) && prod_on) { line_read(ln[2], X2Int<2>{}); line_read(ln[3], X2Int<3>{}); }
+                    }
+                    if (BLK == 2) {
+                        if (q == 0) wdma(c + 1, 7);
+                        if (FIRST && q >= 2 && q <= 5 && !(j & 1)) {
+                            if (prod_on) line_store(ln[q - 2 < 0 ? 0 : (q - 2 > 3 ? 3 : q - 2)], q - 2, c);
+                            else { u32x4 z = {0u, 0u, 0u, 0u}; __builtin_amdgcn_raw_buffer_store_b128(z, grs, 0x7ffffff0, 0, 0); }  // (never: VC is even; keeps the count)
+                        }
+                        if (q == 6) xload(xr[(j + 1) & 3], c + 5, 1);
+                        if (q == 7) xload(xr[(j + 1) & 3], c + 5, 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            block(X2Int<0>{}, bf, X2Int<0>{});   // ah.bh
+            block(X2Int<1>{}, bf, X2Int<1>{});   // am.bh
+            XG2_WAIT8(bn);
+            block(X2Int<0>{}, bn, X2Int<2>{});   // ah.bm
+        }
+    }
+    // the epilogue's pred rows are requested BEFORE the drain below (they ride out the G stores' acknowledgements with it)
+    const int colg[2] = {512 * hp + 256 * wn + 4 * i, 512 * hp + 256 * wn + 128 + 4 * i};
+    const bool colok[2] = {colg[0] < H, colg[1] < H};
+    f32x4 pr[8][2];  // pred rows of this lane's 8 u slots, its 2 x 4 columns (zero where u >= U1 or the column >= H)
+#pragma unroll
+    for (int r7 = 0; r7 < 8; ++r7) {
+        const int u = u0 + 8 * (r7 >> 2) + (r7 & 3) + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            pr[r7][g] = (u < U1 && colok[g]) ? *(const f32x4 *)(a.pred + ((long)b * U1 + u) * H + colg[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float unscale = 4.0f * a.db_rescale * a.scales[1];  // 4 (the tanh' form below) / (g_scale s_W)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued ring loads / DMAs
+    __syncthreads();
+
+    // ---- epilogue (k_dhidden_x3's).  Accumulator register rr = 8rh + r7 of M tile (2wm + mt), column tile q: row (rr&3) +
+    // 8(rr>>2) + 4half of its 32 = t row 2(2wm+mt) + rh, u slot 8(r7>>2) + (r7&3) + 4half; column 512hp + 256wn + 128(q>>2) +
+    // 4i + (q&3).  The tanh' factor 1 - hidden^2 is recomputed from enc and pred: 4 w / (1 + w)^2, w = exp(-2|x|).
+    float (*s_red)[64][65] = (float (*)[64][65])s_dh;  // [wn][lane][8 u slots x 8 columns]
+    const long BTH = (long)a.B * T * H, BUH = (long)a.B * U1 * H;
+    auto dfac_q = [](f2 x) {  // (1 - tanh^2 x) / 4 of two values
+        const f2 a = x * (2.0f * RNNT_LOG2E);
+        const f2 w = {__builtin_amdgcn_exp2f(-__builtin_fabsf(a[0])), __builtin_amdgcn_exp2f(-__builtin_fabsf(a[1]))};
+        const f2 e1 = w + 1.0f;
+        const f2 r = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+        return (w * r) * r;
+    };
+    f2 psum2[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) psum2[k][q] = f2{0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            const int tl = 2 * (2 * wm + mt) + rh;  // t row inside the tile
+            const int t = t0 + tl;
+            f2 esum2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) esum2[q] = f2{0.f, 0.f};
+            f32x4 er[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                er[g] = (t < T && colok[g]) ? *(const f32x4 *)(a.enc + (long)b * a.enc_sb + (long)t * a.enc_st + colg[g]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r7 = 0; r7 < 8; ++r7)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {  // columns 2qq, 2qq+1 of the group
+                        const f2 x = {er[g][2 * qq] + pr[r7][g][2 * qq], er[g][2 * qq + 1] + pr[r7][g][2 * qq + 1]};
+                        const f2 av = {acc[mt][g * 4 + 2 * qq][rh * 8 + r7], acc[mt][g * 4 + 2 * qq + 1][rh * 8 + r7]};
+                        const f2 d = av * dfac_q(x);
+                        esum2[g * 2 + qq] += d;
+                        psum2[r7][g * 2 + qq] += d;
+                    }
+            float esum[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] = unscale * esum2[q >> 1][q & 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) esum[q] += __shfl_xor(esum[q], 32, 64);
+            if (half == 0 && t < Tb) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        const f32x4 o = {esum[g * 4], esum[g * 4 + 1], esum[g * 4 + 2], esum[g * 4 + 3]};
+                        *(f32x4 *)(a.slab_enc + (long)ub * BTH + ((long)b * T + t) * H + colg[g]) = o;
+                    }
+            }
+        }
+    float psum[8][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) psum[k][q] = unscale * psum2[k][q >> 1][q & 1];
+    if (wm == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_red[wn][lane][k * 8 + q] = psum[k][q];
+    }
+    __syncthreads();
+    if (wm == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int u = u0 + 8 * (k >> 2) + (k & 3) + 4 * half;
+            if (u < U1) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (colok[g]) {
+                        f32x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = psum[k][g * 4 + q] + s_red[wn][lane][k * 8 + g * 4 + q];
+                        *(f32x4 *)(a.slab_pred + (long)tt * BUH + ((long)b * U1 + u) * H + colg[g]) = o;
+                    }
+            }
+        }
+    }
+}
+
+bool x2_dhidden_ok(int U1, int H, int V)
+{
+    // raw buffers over one tile's logits rows (32-bit byte offsets), W pack addressing
+    return (long)((XG2_BT - 1) * (long)U1 + XG2_BU) * V * 4 < 0x7fffffffL && V % 128 == 0 && H % 128 == 0;
+}
+
+void launch_dhidden_x2(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = 2 * XG2_WSLOT + 2 * XG2_XSLOT;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    dim3 grid(a.n_ublk16, (a.T + XG2_BT - 1) / XG2_BT, a.B);
+    hipLaunchKernelGGL(k_dhidden_x2<true>, grid, dim3(256), lds, st, a, 0);
+    for (int hp = 1; hp * 512 < a.H; ++hp) hipLaunchKernelGGL(k_dhidden_x2<false>, grid, dim3(256), lds, st, a, hp);
+}
+
+// (to come: the fused forward kernel; until then that stage runs on the fp32 route's kernel + the plain producer)
+bool x2_fwd_ok(int, int, int) { return false; }
+size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H / 16) * 2 * 16 * 64 * 16; }
 void launch_x2_pack_w(const X3Args &a, float *scales, hipStream_t st)
 {
     hipLaunchKernelGGL(k_x2_wscale, dim3(1), dim3(1024), 0, st, a.W, (long)a.V * a.H / 4, scales);
+    const long nd = (long)((a.H + 511) / 512) * (a.V / 16) * 16 * 64;
+    hipLaunchKernelGGL(k_x2_pack_w_dh, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a.W, (const float *)scales, (u32x4 *)a.wpack_dh, a.H, a.V, nd);
 }
 void launch_joint_fwd_x2(const X3Args &, hipStream_t) {}
-void launch_dhidden_x2(const X3Args &, hipStream_t) {}
