@@ -872,13 +872,384 @@ void launch_dhidden_x2(const X3Args &a, hipStream_t st)
     for (int hp = 1; hp * 512 < a.H; ++hp) hipLaunchKernelGGL(k_dhidden_x2<false>, grid, dim3(256), lds, st, a, hp);
 }
 
-// (to come: the fused forward kernel; until then that stage runs on the fp32 route's kernel + the plain producer)
-bool x2_fwd_ok(int, int, int) { return false; }
+// ---------------------------------------------------------------------------------------
+// W (scaled by s_W) for the forward product, fragment order, two planes:
+//   [pass (512 logits columns)][c (16-deep k-step)][plane][tile(16)][lane] x 8 fp16,
+//   element j = piece_plane(s_W W[v = 512pass + 128*(tile>>2) + 4*(lane&31) + (tile&3)][h = 16c + 8*(lane>>5) + j])
+// (columns interleaved by 4, as in the dHidden pack: a lane's 4 tiles of a 128-column group are 4 adjacent logits).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_x2_pack_w_fwd(const float *__restrict__ W, const float *__restrict__ scales, u32x4 *__restrict__ out, int H, int V, long n)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (pass, c, tile, lane): one thread writes both planes
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63), tile = (int)(idx >> 6) & 15;
+    const int KC = H / 16;
+    const int c = (int)((idx >> 10) % KC), pass = (int)((idx >> 10) / KC);
+    const int v = 512 * pass + 128 * (tile >> 2) + 4 * (lane & 31) + (tile & 3);
+    const int h0 = 16 * c + 8 * (lane >> 5);
+    const float sw = scales[0];
+    u32x4 ph = {0u, 0u, 0u, 0u}, pm = ph;
+    if (v < V) {
+        const float *w = W + (long)v * H + h0;
+        f32x4 w0 = *(const f32x4 *)w, w1 = *(const f32x4 *)(w + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w0[k] = x2_clamp(w0[k] * sw); w1[k] = x2_clamp(w1[k] * sw); }
+        X2_SPLIT4(w0, ph, pm, 0);
+        X2_SPLIT4(w1, ph, pm, 2);
+    }
+    u32x4 *o = out + ((long)pass * KC + c) * 2048 + tile * 64 + lane;
+    o[0] = ph; o[1024] = pm;
+}
 size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H / 16) * 2 * 16 * 64 * 16; }
+
+// ---------------------------------------------------------------------------------------
+// k_joint_fwd_x2: k_joint_fwd_x3 on two planes.  hidden = 2^14 tanh(enc + pred) split into its two fp16 planes (produced per
+// k-step in fragment order by the lane that owns the slot), logits = hidden . W^T + bias (fp32, stored), log-softmax statistics
+// and the two log-probs per lattice cell (as the fp32 route's forward).  Tile = 128 consecutive cells; 4 waves = 2 (M) x 2 (N),
+// wave tile 64 cells x 256 columns = 16 accumulator tiles (256 registers); a pass = 512 logits columns, passes run back to
+// back over one linear k-step sequence.  Per k-step ONE barrier, then 3 products x 16 MFMAs:
+//      block 0  ah.bh   + the 8 fragment reads of W's mid plane + A(cs+1): the tanh pieces
+//      block 1  am.bh   + W DMAs 0-3 of k-step cs+1 + A(cs+1): the split pieces;   then the operand loads of k-step cs+2
+//      block 2  ah.bm   + W DMAs 4-7 + A(cs+1): the two ring writes;               then (first pass) the 2 hidden stores
+// (memory operations unconditional and in one fixed order per k-step: every vmcnt is a count).
+// The accumulators hold 2^14 s_W (logits - bias): the pass end multiplies by 2^-14 / s_W and adds the bias (one fma; the bias
+// cannot ride in the accumulators' initial value here: the padding columns' -1e30 would overflow under the scale).
+// Persistent workgroups, one per CU (83 KiB of LDS), tiles from one atomic counter.  Requires H % 128 == 0, V % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define XF2_WSLOT 32768
+#define XF2_ASLOT 8192
+__global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int ntiles)
+{
+    // [0, 64 KiB): W ring;  [64, 80 KiB): A ring;  then: s_den[128], s_part[2][128][2], s_next[2]
+    extern __shared__ __attribute__((aligned(1024))) char s_fw[];
+    float *s_den = (float *)(s_fw + 2 * XF2_WSLOT + 2 * XF2_ASLOT);
+    float *s_part = s_den + 128;  // [wn][row][max, sum]
+    int *s_next = (int *)(s_part + 512);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int H = a.H, V = a.V, KC = H / 16, U1 = a.U1, T = a.T;
+    const int npass = (V + 511) / 512;
+    const int NS = npass * KC;  // k-steps of a tile
+    const long cells = (long)a.B * T * U1;
+    const float unscale = X2_INV_SH * a.scales[1];
+
+    const int lds0 = (int)(size_t)(lds_vptr)s_fw;
+    const int xa = lds0 + 2 * XF2_WSLOT + (2 * wm) * 2048 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
+    const int xw = lds0 + 2 * XF2_WSLOT + wave * 2048 + 16 * lane;       // A write: M tile `wave` (this lane's own fragment slot)
+    const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                  // W read: tiles 8wn .. 8wn+7 of each plane
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, npass * KC * XF2_WSLOT, 0x00020000);
+    const int wvo = lane * 16;
+
+    if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    int tile = s_next[0];
+    for (int it = 1; tile < ntiles; ++it) {
+        if (tid == 0) s_next[it & 1] = (int)atomicAdd(a.counter, 1u);
+        const long row0 = (long)tile * 128;
+        // running (max, sum exp) of every row over the columns seen so far, per column half (wn): s_part[wn][row],
+        // kept by the lanes 31 / 63 that end up with a row slot's wave-level statistics
+        for (int k = tid; k < 256; k += 256) { s_part[2 * k] = RNNT_NEG_INF; s_part[2 * k + 1] = 0.f; }
+        __syncthreads();  // s_next, s_part visible; every wave is past the previous tile's LDS reads
+        const int next = s_next[it & 1];
+        // A tile entirely in the time steps past one utterance's length: its logits are never read (k_dhidden_x2 zero-fills the
+        // G rows of dead tiles itself), but its hidden rows must be finite (k_dw_x2 multiplies them by zeros): such a tile runs
+        // the production of its first pass WITHOUT the MFMAs.
+        bool dead;
+        {
+            const long per = (long)T * U1, c_last = row0 + 127;
+            const long b_first = row0 / per;
+            dead = c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T);
+        }
+
+        // ---- hidden = 2^14 tanh(enc + pred), produced per k-step IN FRAGMENT ORDER by the lane that owns the slot: lane
+        // (i, half) of wave w holds row 32w + i, k = 16c + 8*half .. +7 of the MFMA A operand — 8 values from 2 x 32 bytes of
+        // enc and pred, split two ways, 16 bytes per plane into the LDS ring of k-step c+1 and, in the first pass, to the
+        // hidden planes in memory for k_dw_x2.  Later passes produce it again (the forward never re-reads hidden from memory).
+        const long prow = row0 + 32 * wave + i;
+        const long pc_ = prow < cells ? prow : cells - 1;  // rows past the lattice (last tile): any valid cell, never stored
+        const int pu = (int)(pc_ % U1);
+        const long pbt = pc_ / U1;
+        const int pt = (int)(pbt % T), pb = (int)(pbt / T);
+        const float *ep = a.enc + (long)pb * a.enc_sb + (long)pt * a.enc_st + 8 * half;
+        const float *pp = a.pred + ((long)pb * U1 + pu) * H + 8 * half;
+        // (rows past the lattice produce — and store, unconditionally — the last cell's row again: the same bits to the
+        // same place; hipcc counts vmcnt exactly only through unconditional memory operations)
+        u32x4 *hdst = (u32x4 *)a.hidden + pc_ * (H / 8) + half;  // + 2c: this lane's 16 bytes of k-step c; planes `ps` apart
+        const long ps = a.plane_stride / 8;
+        struct Opd { f32x4 e0, e1, p0, p1; };
+        struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm; };
+        auto op_load = [&](Opd &o, int kcs) {  // operands of k index kcs (inside a pass)
+            o.e0 = *(const f32x4 *)(ep + 16 * kcs); o.e1 = *(const f32x4 *)(ep + 16 * kcs + 4);
+            o.p0 = *(const f32x4 *)(pp + 16 * kcs); o.p1 = *(const f32x4 *)(pp + 16 * kcs + 4);
+        };
+        // pieces 0-7: 2^14 tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 2-way split
+        // of each pair (hi + residuals, then mid); 16: the two ring writes
+        auto prod_piece = [&](Prod &P, const Opd &o, int slot, int k) {
+            if (k < 8) {
+                const int j = k >> 1;
+                if (!(k & 1)) {
+                    const f32x4 &e = j < 2 ? o.e0 : o.e1, &pv = j < 2 ? o.p0 : o.p1;
+                    const int q = 2 * (j & 1);
+                    const f2 x = {e[q] + pv[q], e[q + 1] + pv[q + 1]};
+                    const f2 av = x * (2.0f * RNNT_LOG2E);
+                    P.w[j] = f2{__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+                } else {
+                    const f2 ex = P.w[j] + 1.0f;
+                    const f2 rr = {__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+                    P.w[j] = X2_SH - (2.0f * X2_SH) * rr;  // 2^14 (1 - 2 / (1 + e^2x)): the same rounding as the unscaled form
+                }
+            } else if (k < 16) {
+                const int j = (k - 8) >> 1;
+                if (!(k & 1)) {
+                    const unsigned hh = x2_pack(P.w[j][0], P.w[j][1]);
+                    P.ph[j] = hh;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(P.ra) : "v"(hh), "v"(P.w[j][0]));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(P.rb) : "v"(hh), "v"(P.w[j][1]));
+                } else {
+                    P.pm[j] = x2_pack(P.ra, P.rb);
+                }
+            } else {
+                const int dst = xw + slot * XF2_ASLOT;
+                asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(P.ph) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
+            }
+        };
+        auto hid_store = [&](const Prod &P, int kcs) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; };
+        // piece n (0..7) of this wave's share of W k-step cs -> ring slot cs & 1
+        auto wdma = [&](int cs, int n) {  // raw-buffer form: scalar base and offsets, one constant per-lane offset register
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fw + (cs & 1) * XF2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
+                                                     (cs * 32 + wave * 8 + n) * 1024, 0, 0);
+        };
+
+        if (dead) {  // hidden rows only (finite values for k_dw_x2), no products
+            for (int kc = 0; kc < KC; ++kc) {
+                Opd o; Prod P;
+                op_load(o, kc);
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, 0, pc);
+                hid_store(P, kc);
+            }
+            tile = next;
+            continue;
+        }
+
+        f32x16 acc[2][8];
+        auto acc_init = [&]() {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
+        };
+        // pipeline prologue: W of k-step 0 by DMA; A of k-step 0 produced, stored, written to ring slot 0; operands of
+        // k-step 1 requested
+        Opd oset[2];  // operands of k-step cs+1 live in oset[(cs+1) & 1] during k-step cs (KC is even: the k loop is unrolled by 2)
+        {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) wdma(0, n);
+            Opd o; Prod P;
+            op_load(o, 0);
+            op_load(oset[1], KC > 1 ? 1 : 0);
+#pragma unroll
+            for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, 0, pc);
+            hid_store(P, 0);
+        }
+
+        int cs = 0;
+        // one pass; STORE: the first — the produced planes also go to memory.  Two straight-line instantiations, the first pass
+        // outside the loop over the others (a branch between two k loops, like a conditional accumulator re-initialisation
+        // inside one, makes hipcc carry the 256 accumulator registers through VGPR phis and spill)
+        auto run_pass = [&](auto store_c, const int pass) {
+          acc_init();
+          constexpr bool STORE = decltype(store_c)::value != 0;
+          for (int kc0 = 0; kc0 < KC; kc0 += 2)
+#pragma unroll
+          for (int par = 0; par < 2; ++par, ++cs) {
+            const int kc = kc0 + par;
+            // W of k-step cs landed (this wave's share).  vmcnt retires in order: behind a k-step's last DMA (block 2) come only
+            // the first pass's 2 hidden stores, which stay in flight (the 4 operand loads sit between the two DMA groups and
+            // retire with them); the first k-step of a pass also follows the previous pass's logits stores
+            if (kc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STORE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x2_lds_barrier();  // publishes W slot and A slot of k-step cs; every wave is past its reads of cs-1
+            const int ws = wb + (cs & 1) * XF2_WSLOT, xs = xa + (cs & 1) * XF2_ASLOT;
+            // the next k-step (past the end: its own, never read) and the one after (operand loads)
+            const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
+            const Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
+            Opd &onext = oset[par & 1];             // refilled with those of k-step cs+2
+            Prod P;
+            u32x4 af[2][2], bf[8], bn[8];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 2048 + p * 1024));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
+                           "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
+                         :: "memory");
+            auto block = [&](auto pa_c, const u32x4 (&bcur)[8], auto blk_c) {
+                constexpr int PA = decltype(pa_c)::value, BLK = decltype(blk_c)::value;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc[0][q] = x2_mfma(af[0][PA], bcur[q], acc[0][q]);
+                    acc[1][q] = x2_mfma(af[1][PA], bcur[q], acc[1][q]);
+                    if (BLK == 0) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[q]) : "v"(ws), "n"(16384 + q * 1024));
+                        prod_piece(P, ocur, (cs + 1) & 1, q);
+                    }
+                    if (BLK == 1) {
+                        if (q & 1) wdma(csn, q >> 1);
+                        prod_piece(P, ocur, (cs + 1) & 1, 8 + q);
+                    }
+                    if (BLK == 2) {
+                        if (q & 1) wdma(csn, 4 + (q >> 1));
+                        if (q == 0) prod_piece(P, ocur, (cs + 1) & 1, 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            block(X2Int<0>{}, bf, X2Int<0>{});   // ah.bh
+            block(X2Int<1>{}, bf, X2Int<1>{});   // am.bh
+            op_load(onext, kcnn);  // operands of k-step cs+2: between the DMA groups (they are needed a whole k-step from now)
+            XG2_WAIT8(bn);
+            block(X2Int<0>{}, bn, X2Int<2>{});   // ah.bm
+            if (STORE) hid_store(P, kcn);  // (the youngest memory operations of the k-step; the pass's last k-step re-stores k-step 0)
+            (void)kcn;
+          }
+          // pass complete: unscale, add the bias, store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column
+          // groups exist or not for the whole wave.  The row loop is ONE basic block per case; the store address is a scalar
+          // row pointer + one 32-bit per-lane offset.
+          {
+            const int cw = 512 * pass + 256 * wn;
+            const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
+            char *tile_base = (char *)(a.logits + row0 * V + cw);
+            const f32x4 b0 = cw + 4 * i < V ? *(const f32x4 *)(a.bias + cw + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1 = cw + 128 + 4 * i < V ? *(const f32x4 *)(a.bias + cw + 128 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            auto epilogue = [&](auto both_c) {
+                constexpr bool BOTH = decltype(both_c)::value != 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // accumulator reads spelled as (volatile) asm: they stay here, one row slot at a time — left to
+                        // hipcc, all 256 v_accvgpr_read are hoisted in front of the first store and spilled
+                        f32x4 o0, o1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float x0, x1;
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[mt][q][r]));
+                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[mt][4 + q][r]));
+                            o0[q] = fmaf(x0, unscale, b0[q]); o1[q] = fmaf(x1, unscale, b1[q]);
+                        }
+                        char *rowp = tile_base + (long)(32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2)) * V * 4;  // wave-uniform
+                        __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
+                        if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
+                        {
+                            // the row slot's (max, sum exp) over this wave's 128 / 256 columns of the pass: 8 values per
+                            // lane, then the 32 lanes of the half on the DPP crossbar
+                            float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
+                            if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                            const float M = half_max_dpp(m8, half);
+                            const float nm2 = -M * RNNT_LOG2E;
+                            float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                                      (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                            if (BOTH)
+                                e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                                     (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                            const float S_ = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
+                            if (i == 31) {
+                                float *sp = s_part + (wn * 128 + 32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
+                                const float m_o = sp[0], s_o = sp[1];
+                                const float mn = fmaxf(m_o, M);
+                                sp[0] = mn;
+                                sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
+                    }
+            };
+            if (cw + 128 < V) epilogue(X2Int<1>{});
+            else if (cw < V) epilogue(X2Int<0>{});
+          }
+        };
+        run_pass(X2Int<1>{}, 0);
+        for (int pass = 1; pass < npass; ++pass) run_pass(X2Int<0>{}, pass);
+
+        // ---- log-softmax denominators: the two column halves (wn) of every row
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every logits / hidden store of the workgroup has left its wave; s_part complete
+        if (tid < 128) {
+            const float m0 = s_part[tid * 2], s0 = s_part[tid * 2 + 1];
+            const float m1 = s_part[(128 + tid) * 2], s1 = s_part[(128 + tid) * 2 + 1];
+            const float M = fmaxf(m0, m1);
+            const float S_ = s0 * __builtin_amdgcn_exp2f((m0 - M) * RNNT_LOG2E) + s1 * __builtin_amdgcn_exp2f((m1 - M) * RNNT_LOG2E);
+            s_den[tid] = M + __logf(S_);
+        }
+        __syncthreads();
+        // thread = (row = tid & 127, which = tid >> 7): logit[blank] / logit[label] of the row, read through L2
+        // (agent-scope loads bypass the CU's vector L1; the stores above are complete: vmcnt(0) + barrier)
+        {
+            const int row = tid & 127, which = tid >> 7;
+            const long cell = row0 + row;
+            if (cell < cells) {
+                const int u = (int)(cell % U1);
+                const long bt = cell / U1;
+                const int t = (int)(bt % T), b = (int)(bt / T);
+                const int Ub = len_u(a.target_lens, b, U1);
+                if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
+                    const float den = s_den[row];
+                    const float *lrow = a.logits + cell * V;
+                    const long si = skew_index(b, t, u, a.D, U1);
+                    if (which == 0) {
+                        const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.denom_s[si] = den;
+                        a.lpb_s[si] = lb - den;
+                    } else {
+                        float le = 0.f;
+                        if (u < Ub) {
+                            const int y = a.targets[(long)b * (U1 - 1) + u];
+                            le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                        }
+                        a.lpe_s[si] = le;
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+}
+
+bool x2_fwd_ok(int U1, int H, int V) { return H % 128 == 0 && V % 128 == 0 && (long)128 * H * 2 < 0x7fffffffL; }
+
+void launch_joint_fwd_x2(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = 2 * XF2_WSLOT + 2 * XF2_ASLOT + 128 * 4 + 2 * 128 * 2 * 4 + 16;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_joint_fwd_x2, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const long cells = (long)a.B * a.T * a.U1;
+    const int ntiles = (int)((cells + 127) / 128);
+    launch_fill32(a.counter, 0u, 4, st);  // tile counter of the persistent workgroups
+    const int nwg = ntiles < a.n_cu ? ntiles : a.n_cu;  // one workgroup per CU
+    hipLaunchKernelGGL(k_joint_fwd_x2, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+}
+
 void launch_x2_pack_w(const X3Args &a, float *scales, hipStream_t st)
 {
     hipLaunchKernelGGL(k_x2_wscale, dim3(1), dim3(1024), 0, st, a.W, (long)a.V * a.H / 4, scales);
     const long nd = (long)((a.H + 511) / 512) * (a.V / 16) * 16 * 64;
     hipLaunchKernelGGL(k_x2_pack_w_dh, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, a.W, (const float *)scales, (u32x4 *)a.wpack_dh, a.H, a.V, nd);
+    const long nf = (long)((a.V + 511) / 512) * (a.H / 16) * 16 * 64;
+    hipLaunchKernelGGL(k_x2_pack_w_fwd, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, a.W, (const float *)scales, (u32x4 *)a.wpack_fwd, a.H, a.V, nf);
 }
-void launch_joint_fwd_x2(const X3Args &, hipStream_t) {}
