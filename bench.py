@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)   # >= 5 warm-ups, median of >= 20
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3"],
+    ap.add_argument("--dtype", default="bf16x3", choices=["fp32", "bf16", "bf16x3", "f16x2"],
                     help="bf16x3 (default) = fp32-ACCURATE results from six bf16 MFMA products of 3-way split operands "
                          "(RNNT_DTYPE_F32_BF16X3: the fp32 route's 1e-4 parity bar, every fp32 parity test runs on it); "
                          "fp32 = exact fp32 products on v_mfma_f32_32x32x2_f32 (1/16 of the bf16 matrix rate); "
@@ -370,9 +370,10 @@ def main():
         "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
         "arith": {"fp32": "v_mfma_f32_32x32x2_f32 (exact fp32 products)",
                   "bf16x3": "6 x v_mfma_f32_32x32x16_bf16 per fp32 product (operands split hi+mid+lo), fp32 accumulate",
+                  "f16x2": "3 x v_mfma_f32_32x32x16_f16 per fp32 product (operands scaled by powers of two and split hi+mid: 22 significant bits), fp32 accumulate",
                   "bf16": "v_mfma_f32_32x32x16_bf16 on bf16-rounded operands, fp32 accumulate, fp16 logits"}[args.dtype],
         "config": {"workload": f"{args.config}: B={B},T={T},U={U},H={H},V={V} " +
-                               {"fp32": "fp32", "bf16": "bf16", "bf16x3": "fp32-accurate (bf16x3 arithmetic)"}[args.dtype] +
+                               {"fp32": "fp32", "bf16": "bf16", "bf16x3": "fp32-accurate (bf16x3 arithmetic)", "f16x2": "fp32-class (f16x2 arithmetic)"}[args.dtype] +
                                " joint+loss fwd+bwd" +
                                (", enc = permuted (N,C,L) view" if args.permuted_enc else ""),
                    "enc_layout": "permute(0,2,1) view of (N,C,L), as rnnt/model.py:27-28" if args.permuted_enc else "contiguous (B,T,H)",
@@ -394,11 +395,13 @@ def main():
         gemms = {k: stage_ms[k] for k in ("joint_fwd_gemm", "dhidden_gemm", "dw_gemm")}
         dom = max(gemms, key=gemms.get)
         ach = 2.0 * H * V * cells1 / (gemms[dom] * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype != "bf16x3" else PEAK_BF16_MFMA_TFLOPS / 6.0
+        peak = {"bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0, "f16x2": PEAK_BF16_MFMA_TFLOPS / 3.0}.get(args.dtype, PEAK_F32_MFMA_TFLOPS)
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach,
                            "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": None,
                            "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
+        if args.dtype == "f16x2":
+            out["roofline"]["peak_note"] = "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 products per fp32 product (fp32-equivalent flops)"
         if args.dtype == "bf16x3":
             out["roofline"]["peak_note"] = "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 products per fp32 product (fp32-equivalent flops)"
         if args.dtype == "bf16":

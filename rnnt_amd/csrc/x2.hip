@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         };
         // pieces 0-7: 2^14 tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 2-way split
         // of each pair (hi + residuals, then mid); 16: the two ring writes
-        auto prod_piece = [&](Prod &P, const Opd &o, int slot, int k) {
+        auto prod_piece = [&](Prod &P, const Opd &o, auto off_c, int k) {  // off_c: byte offset of the target A slot in the ring
             if (k < 8) {
                 const int j = k >> 1;
                 if (!(k & 1)) {
@@ -1011,9 +1011,9 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                     P.pm[j] = x2_pack(P.ra, P.rb);
                 }
             } else {
-                const int dst = xw + slot * XF2_ASLOT;
-                asm volatile("ds_write_b128 %0, %1" :: "v"(dst), "v"(P.ph) : "memory");
-                asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(dst), "v"(P.pm) : "memory");
+                const int dst = xw;  // (a local: asm operands cannot name a capture of the enclosing generic lambda)
+                asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(dst), "v"(P.ph), "n"(decltype(off_c)::value) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(dst), "v"(P.pm), "n"(decltype(off_c)::value + 1024) : "memory");
             }
         };
         auto hid_store = [&](const Prod &P, int kcs) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; };
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                 Opd o; Prod P;
                 op_load(o, kc);
 #pragma unroll
-                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, 0, pc);
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
                 hid_store(P, kc);
             }
             tile = next;
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             op_load(o, 0);
             op_load(oset[1], KC > 1 ? 1 : 0);
 #pragma unroll
-            for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, 0, pc);
+            for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
             hid_store(P, 0);
         }
 
@@ -1065,10 +1065,11 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         auto run_pass = [&](auto store_c, const int pass) {
           acc_init();
           constexpr bool STORE = decltype(store_c)::value != 0;
-          for (int kc0 = 0; kc0 < KC; kc0 += 2)
-#pragma unroll
-          for (int par = 0; par < 2; ++par, ++cs) {
-            const int kc = kc0 + par;
+          // one k-step; PAR = its parity = its ring slots (KC is even: cs and kc have the same parity): compile-time, so that
+          // every LDS access is ONE base register + an immediate (distinct base registers per slot were spilled, and a reload
+          // behind the DMAs waits vmcnt(0))
+          auto kstep = [&](auto par_c, const int kc) {
+            constexpr int par = decltype(par_c)::value;
             // W of k-step cs landed (this wave's share).  vmcnt retires in order: behind a k-step's last DMA (block 2) come only
             // the first pass's 2 hidden stores, which stay in flight (the 4 operand loads sit between the two DMA groups and
             // retire with them); the first k-step of a pass also follows the previous pass's logits stores
@@ -1076,7 +1077,8 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             else if (STORE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             x2_lds_barrier();  // publishes W slot and A slot of k-step cs; every wave is past its reads of cs-1
-            const int ws = wb + (cs & 1) * XF2_WSLOT, xs = xa + (cs & 1) * XF2_ASLOT;
+            constexpr int WS = par * XF2_WSLOT, XS = par * XF2_ASLOT, XN = (1 - par) * XF2_ASLOT;
+            const int ws = wb, xs = xa;
             // the next k-step (past the end: its own, never read) and the one after (operand loads)
             const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
             const Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
@@ -1087,9 +1089,9 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(mt * 2048 + p * 1024));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[mt][p]) : "v"(xs), "n"(XS + mt * 2048 + p * 1024));
 #pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(q * 1024));
+            for (int q = 0; q < 8; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[q]) : "v"(ws), "n"(WS + q * 1024));
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]),
                            "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7])
@@ -1101,16 +1103,16 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                     acc[0][q] = x2_mfma(af[0][PA], bcur[q], acc[0][q]);
                     acc[1][q] = x2_mfma(af[1][PA], bcur[q], acc[1][q]);
                     if (BLK == 0) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[q]) : "v"(ws), "n"(16384 + q * 1024));
-                        prod_piece(P, ocur, (cs + 1) & 1, q);
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[q]) : "v"(ws), "n"(WS + 16384 + q * 1024));
+                        prod_piece(P, ocur, X2Int<XN>{}, q);
                     }
                     if (BLK == 1) {
                         if (q & 1) wdma(csn, q >> 1);
-                        prod_piece(P, ocur, (cs + 1) & 1, 8 + q);
+                        prod_piece(P, ocur, X2Int<XN>{}, 8 + q);
                     }
                     if (BLK == 2) {
                         if (q & 1) wdma(csn, 4 + (q >> 1));
-                        if (q == 0) prod_piece(P, ocur, (cs + 1) & 1, 16);
+                        if (q == 0) prod_piece(P, ocur, X2Int<XN>{}, 16);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1122,7 +1124,9 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             block(X2Int<0>{}, bn, X2Int<2>{});   // ah.bm
             if (STORE) hid_store(P, kcn);  // (the youngest memory operations of the k-step; the pass's last k-step re-stores k-step 0)
             (void)kcn;
-          }
+            ++cs;
+          };
+          for (int kc0 = 0; kc0 < KC; kc0 += 2) { kstep(X2Int<0>{}, kc0); kstep(X2Int<1>{}, kc0 + 1); }
           // pass complete: unscale, add the bias, store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column
           // groups exist or not for the whole wave.  The row loop is ONE basic block per case; the store address is a scalar
           // row pointer + one 32-bit per-lane offset.
