@@ -288,7 +288,8 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         {   // f16x2 operand scales: |G| <= grad_scale <= 2^e -> g_scale = 2^(13 - e); hidden: 2^14 (x2.hip)
             int e = 0;
             (void)frexpf(grad_scale, &e);
-            h.g_scale = ldexpf(1.0f, 13 - e);
+            const int k = 13 - e < -100 ? -100 : (13 - e > 100 ? 100 : 13 - e);
+            h.g_scale = ldexpf(1.0f, k);
             h.dw_rescale = 1.0f / (h.g_scale * 16384.0f); h.db_rescale = 1.0f / h.g_scale;
             h.scales = (const float *)(ws + L.counters + 640);
         }

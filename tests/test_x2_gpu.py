@@ -1,0 +1,153 @@
+"""-m gpu: what is specific to the RNNT_DTYPE_F32_F16X2 route (rnnt_amd/csrc/x2.hip: fp32-class products as THREE fp16
+MFMA products of power-of-two-scaled, 2-way split operands — half the matrix work of the bf16x3 route).  Like bf16x3 the
+route is held to EXACTLY the fp32 route's bar by tests/test_gpu_parity.py itself (the `route` fixture: shape list,
+ragged / random / poisoned batches, the golden fixtures, configs 1, 2, 4 and 5 at full size, 1e-4 against the plain fp64
+oracle).  Here: each f16x2 kernel in isolation (the other stages on the fp32 route's kernels + the plain split kernels),
+its measured error beside the fp32-MFMA route's, the operand scales (grad_scale and |W| over 12 orders of magnitude),
+dense full-size data against the fp32-MFMA route, reproducibility, the C boundary's checks."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import (GRAD_RTOL, LOSS_RTOL, assert_close_grad, assert_close_loss, make_inputs, oracle_fused)
+from tests.test_gpu_parity import _dev, _run_fused
+
+pytestmark = pytest.mark.gpu
+X2 = "f16x2"
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import rnnt_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    rnnt_amd.engine.lib()
+    return rnnt_amd
+
+
+@pytest.mark.parametrize("variant", ["dw_only", "dw_dhidden", "all"])
+@pytest.mark.parametrize("shape", [(2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024), (2, 13, 20, 1024, 256),
+                                   (3, 21, 9, 640, 128), (2, 130, 50, 512, 256)])
+def test_x2_kernels_in_isolation(amd, variant, shape):
+    """With RNNT_VARIANT_X3_FP32_FWD | _DH only k_dw_x2 runs (forward and dHidden on the fp32 route's kernels, k_x2_make_hidden
+    / k_x2_split_g in between), with _FWD alone k_dhidden_x2 + k_dw_x2, without a variant all three — each against the fp64
+    oracle at the fp32 tolerances."""
+    e = amd.engine
+    var = {"dw_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH, "dw_dhidden": e.VARIANT_X3_FP32_FWD, "all": 0}[variant]
+    B, T, U, H, V = shape
+    d = make_inputs(B, T, U, H, V, seed=sum(shape))
+    g = _dev(d)
+    outs = e.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"], g["target_lens"],
+                                V - 1, 1.0 / B, dtype=X2, variant=var)
+    torch.cuda.synchronize()
+    ref = oracle_fused(d)
+    assert_close_loss("costs", outs[0].cpu().numpy(), ref["costs"])
+    for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")):
+        assert_close_grad(k, o.cpu().numpy(), ref[k])
+
+
+def _errors(amd, d, ref, dt):
+    r = _run_fused(amd, d, dt)
+    err = {k: float(np.abs(r[k] - ref[k]).max() / np.abs(ref[k]).max()) for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias")}
+    err["loss"] = abs(r["loss"] - ref["loss"]) / abs(ref["loss"])
+    return err
+
+
+def test_x2_error_beside_the_fp32_mfma_route(amd):
+    """The three fp32-bar routes against the fp64 oracle on the same inputs (a lattice of 10 k cells at config 2's H, V): the
+    f16x2 route's error is of the fp32-MFMA route's class — within 2.5x of it (or of one fp32 rounding, 6e-8, where that
+    route is more accurate than a single rounding), 20x inside the 1e-4 bar (the numbers go to stdout for DESIGN.md)."""
+    d = make_inputs(4, 100, 24, 512, 1024, seed=1234)
+    ref = oracle_fused(d)
+    err = {dt: _errors(amd, d, ref, dt) for dt in ("fp32", "bf16x3", X2)}
+    print("\nerror vs fp64 oracle:", {dt: {k: "%.1e" % v for k, v in e.items()} for dt, e in err.items()})
+    for k, v in err[X2].items():
+        assert v < 0.05 * GRAD_RTOL, (k, v)
+        assert v < 2.5 * max(err["fp32"][k], 6e-8), (k, v, err["fp32"][k])
+
+
+@pytest.mark.parametrize("w_mag,grad_scale", [(1e-6, 1.0), (1e3, 1.0 / 4), (0.05, 1e-6), (0.05, 4096.0), (30.0, 3e-4)])
+def test_x2_operand_scales(amd, w_mag, grad_scale):
+    """fp16's 5-bit exponent: the route scales W by a power of two found from max |W| on the device (k_x2_wscale) and G by
+    one derived from grad_scale (|G| <= grad_scale), hidden by 2^14.  Weights of magnitude 1e-6 .. 1e3 and grad_scale
+    1e-6 .. 4096 keep the fp32-class error (relative to each gradient's own largest entry; beside the exact-fp32 route's
+    where the problem itself is ill-conditioned in fp32)."""
+    B, T, U, H, V = 2, 30, 9, 256, 384
+    d = make_inputs(B, T, U, H, V, seed=77)
+    d["W"] = (d["W"] / np.abs(d["W"]).max() * w_mag).astype(np.float32)
+    # (large |W| saturate the softmax: keep the logits O(1) by shrinking the activations' reach through the bias only;
+    # the hidden operand is tanh(.) in [-1, 1] whatever enc and pred hold)
+    g = _dev(d)
+    run = lambda dt: [o.cpu().numpy().astype(np.float64) for o in amd.engine.joint_loss_fwd_bwd(
+        g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"], g["target_lens"], V - 1, grad_scale, dtype=dt)]
+    outs, outs32 = run(X2), run("fp32")
+    ref = oracle_fused(d)  # gradients of the MEAN loss: linear in grad_scale
+    assert_close_loss("costs", outs[0], ref["costs"])
+    for o, o32, k in zip(outs[1:], outs32[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")):
+        want = ref[k] * (grad_scale * B)
+        assert np.isfinite(o).all(), k
+        err, err32 = (float(np.abs(x - want).max() / np.abs(want).max()) for x in (o, o32))
+        # (|W| ~ 1e3 puts the logits in the thousands: there the exact-fp32 route itself is only good to ~1e-3)
+        assert err < max(0.05 * GRAD_RTOL, 3.0 * err32), (k, err, err32)
+
+
+def test_x2_zero_weights_and_huge_inputs(amd):
+    """W == 0 (scale falls back to 1) and activations far outside tanh's linear range (hidden saturates at +-1 = +-2^14
+    scaled: inside fp16) — finite, parity-true results."""
+    B, T, U, H, V = 2, 12, 5, 128, 128
+    d = make_inputs(B, T, U, H, V, seed=5)
+    d["W"][:] = 0.0
+    d["enc"] *= 1e4
+    g = _dev(d)
+    outs = amd.engine.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"], g["target_lens"],
+                                         V - 1, 0.5, dtype=X2)
+    ref = oracle_fused(d)
+    assert_close_loss("costs", outs[0].cpu().numpy(), ref["costs"])
+    for o, k in zip(outs[1:], ("grad_enc", "grad_pred", "grad_W", "grad_bias")):
+        assert_close_grad(k, o.cpu().numpy(), ref[k] * (0.5 * B))
+
+
+def test_x2_fullsize_config2_vs_fp32(amd):
+    """BASELINE config 2 at full size (B=32,T=1000,U=200,H=512,V=1024): dense ragged data against the fp32-MFMA route at the
+    fp32 tolerances (row offsets beyond 2^31 bytes, every tile / pass / split)."""
+    d = make_inputs(32, 1000, 200, 512, 1024, seed=32)
+    amd.engine.release_workspaces()
+    ref = _run_fused(amd, d, "fp32")
+    amd.engine.release_workspaces()
+    r = _run_fused(amd, d, X2)
+    amd.engine.release_workspaces()
+    assert_close_loss("costs", r["costs"], ref["costs"], rtol=LOSS_RTOL)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r[k], ref[k], rtol=GRAD_RTOL)
+
+
+def test_x2_reference_joint_width_vs_fp32(amd):
+    """The reference's real joint width (hidden_features: 1024: a second dHidden launch reads G's planes back) at a
+    training-sized ragged batch, against the fp32-MFMA route."""
+    d = make_inputs(8, 500, 100, 1024, 1024, seed=11)
+    ref = _run_fused(amd, d, "fp32")
+    r = _run_fused(amd, d, X2)
+    assert_close_loss("costs", r["costs"], ref["costs"], rtol=LOSS_RTOL)
+    for k in ("grad_enc", "grad_pred", "grad_W", "grad_bias"):
+        assert_close_grad(k, r[k], ref[k], rtol=GRAD_RTOL)
+    amd.engine.release_workspaces()
+
+
+def test_x2_is_bitwise_reproducible(amd):
+    """Fixed summation orders: two calls agree bit for bit (graph capture: tests/test_gpu_parity.py)."""
+    B, T, U, H, V = 3, 40, 12, 256, 512
+    g = _dev(make_inputs(B, T, U, H, V, seed=501))
+    run = lambda: amd.engine.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"],
+                                                g["target_lens"], V - 1, 0.25, dtype=X2)
+    a = [o.clone() for o in run()]
+    b = [o.clone() for o in run()]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_x2_rejects_unsupported_dims_at_the_c_abi(amd):
+    """include/rnnt_engine.h: RNNT_DTYPE_F32_F16X2 needs H % 128 == 0 and V % 128 == 0 at the C boundary (the Python operator pads)."""
+    d = make_inputs(2, 9, 4, 64, 128, seed=1)
+    g = _dev(d)
+    with pytest.raises(RuntimeError, match="RNNT_DTYPE_F32_F16X2"):
+        amd.engine.joint_loss_fwd_bwd(g["enc"], g["pred"], g["W"], g["bias"], g["targets"], g["logit_lens"],
+                                      g["target_lens"], 127, 0.5, dtype=X2)
