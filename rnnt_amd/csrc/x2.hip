@@ -182,7 +182,7 @@ void launch_x2_zero_padding(const X3Args &a, int what, hipStream_t st)
 // k_dw_x2: dW[v,h] = sum_c G[c,v] hidden[c,h] (split-K slabs), db[v] = sum_c G[c,v] — k_dw_x3's design on two planes:
 // 4 waves = 2 (M) x 2 (N), workgroup tile 256 v x 256 h, wave 128 x 128 = 16 accumulator tiles (256 registers).  Both
 // operands row-major with K (the cell) as the ROW, two fp16 planes each:
-//  * HBM -> LDS by LDS-DMA, ring of 3 stages of 16 cells x (256 v + 256 h) x 2 planes = 32 KiB; wave w fills operand tile w
+//  * HBM -> LDS by LDS-DMA, ring of XW2_NST (4) stages of 16 cells x (256 v + 256 h) x 2 planes = 32 KiB; wave w fills operand tile w
 //    (0,1: the 128-column halves of the G tile, 2,3: of the hidden tile), 8 DMAs of 1 KiB (4 rows x 256 B) per stage;
 //  * LDS -> VGPR by ds_read_b64_tr_b16 (4x16 transpose read): two reads give a lane its 8 consecutive cells of one column;
 //  * tile image: 256-byte rows, 16-byte chunk ch of row r at 16*(ch ^ swz(r)), swz(r) = ((r&3)<<2) | ((r>>2)&3), applied
@@ -193,7 +193,9 @@ void launch_x2_zero_padding(const X3Args &a, int what, hipStream_t st)
 // The accumulators hold g_scale x 2^14 x dW: the epilogue multiplies by X3Args::dw_rescale (a power of two).
 // ---------------------------------------------------------------------------------------
 #define XW2_ROWS 16
-#define XW2_NST 3
+#ifndef XW2_NST
+#define XW2_NST 4   // ring stages: the DMAs of stage ks + NST - 1 are issued during k-step ks
+#endif
 #define XW2_PLANE 4096            // one operand tile of one plane: 16 rows x 256 B
 #define XW2_STAGE (2 * XW2_PLANE)  // one stage of one operand tile
 #define XW2_TILE (XW2_NST * XW2_STAGE)  // ring of one operand tile: [stage][plane][16 x 256 B] = 24 KiB
@@ -302,12 +304,12 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
 
         // one k-step on ring stage ST (compile-time: every LDS offset is an immediate)
         auto kstep = [&](auto st_c, long ks, f32x16 &dacc) {
-            constexpr int ST = decltype(st_c)::value, DST = (ST + 2) % 3;
+            constexpr int ST = decltype(st_c)::value, DST = (ST + XW2_NST - 1) % XW2_NST;
             // the 16 rows of stage ks+2 as two raw buffers (wave-uniform base; the per-lane part is the 32-bit soff)
             __amdgpu_buffer_rsrc_t rs[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                rs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (ks + 2) * XW2_ROWS) * rstride), 0,
+                rs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (ks + XW2_NST - 1) * XW2_ROWS) * rstride), 0,
                                                           (int)(XW2_ROWS * rstride), 0x00020000);
             auto dma_piece = [&](auto n_c) {  // piece n of stage ks+2 -> ring stage DST: plane n>>2, rows 4(n&3)..
                 constexpr int n = decltype(n_c)::value, p = n >> 2, i = n & 3;
@@ -357,9 +359,10 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
                 // accumulator in VGPRs, spelled as asm (left to hipcc the 17th tile is shuttled through the full AGPR file)
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dacc) : "v"(fa), "v"(sel));
             };
-            // stage ks landed (the 8 younger pieces of ks+1 may still fly); every wave is past its reads of stage ks-1,
-            // whose ring stage the DMAs below refill
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // stage ks landed (the 8 (NST - 2) younger pieces of the stages after it may still fly); every wave is past its reads of
+            // stage ks-1, whose ring stage the DMAs below refill
+            if (XW2_NST == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             x2_lds_barrier();
             X2Frag Ah, Bh, Am, Bm;
             u32x2 dl[2], dh[2];
@@ -405,13 +408,18 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
             gq = ge;
             dma_stage(0, 0);
             dma_stage(1, 1);
-            for (long ks = 0;;) {  // the ring stage of a k-step is ks % 3: unrolled by 3
+            if (XW2_NST == 4) dma_stage(2, 2);
+            for (long ks = 0;;) {  // the ring stage of a k-step is ks % NST: unrolled by NST
                 if (ks >= nks) break;
                 kstep(X2Int<0>{}, ks, dacc); ++ks;
                 if (ks >= nks) break;
                 kstep(X2Int<1>{}, ks, dacc); ++ks;
                 if (ks >= nks) break;
                 kstep(X2Int<2>{}, ks, dacc); ++ks;
+                if (XW2_NST == 4) {
+                    if (ks >= nks) break;
+                    kstep(X2Int<3 % XW2_NST>{}, ks, dacc); ++ks;
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the ring
             x2_lds_barrier();                                  // is refilled / the kernel exits
@@ -918,6 +926,20 @@ size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
 // ---------------------------------------------------------------------------------------
 #define XF2_WSLOT 32768
 #define XF2_ASLOT 8192
+#ifdef RNNT_STAMPS
+// Diagnostic build only (-DRNNT_STAMPS): s_memtime stamps of workgroup 0, wave 0, k-steps 8..23 of its first tile:
+// debug[(step-8)*8 + slot] (tools/exp_x3_stamps.py)
+#define X2STAMP(slot)                                                                                       \
+    do {                                                                                                    \
+        if (a.debug && blockIdx.x == 0 && wave == 0 && lane == 0 && it == 1 && cs >= 8 && cs < 24) {         \
+            unsigned long long t_;                                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+            a.debug[(cs - 8) * 8 + (slot)] = t_;                                                            \
+        }                                                                                                   \
+    } while (0)
+#else
+#define X2STAMP(slot) do {} while (0)
+#endif
 __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int ntiles)
 {
     // [0, 64 KiB): W ring;  [64, 80 KiB): A ring;  then: s_den[128], s_part[2][128][2], s_next[2]
@@ -1073,10 +1095,13 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             // W of k-step cs landed (this wave's share).  vmcnt retires in order: behind a k-step's last DMA (block 2) come only
             // the first pass's 2 hidden stores, which stay in flight (the 4 operand loads sit between the two DMA groups and
             // retire with them); the first k-step of a pass also follows the previous pass's logits stores
+            X2STAMP(0);
             if (kc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (STORE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            X2STAMP(1);
             x2_lds_barrier();  // publishes W slot and A slot of k-step cs; every wave is past its reads of cs-1
+            X2STAMP(2);
             constexpr int WS = par * XF2_WSLOT, XS = par * XF2_ASLOT, XN = (1 - par) * XF2_ASLOT;
             const int ws = wb, xs = xa;
             // the next k-step (past the end: its own, never read) and the one after (operand loads)
@@ -1117,12 +1142,16 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            X2STAMP(3);
             block(X2Int<0>{}, bf, X2Int<0>{});   // ah.bh
+            X2STAMP(4);
             block(X2Int<1>{}, bf, X2Int<1>{});   // am.bh
+            X2STAMP(5);
             op_load(onext, kcnn);  // operands of k-step cs+2: between the DMA groups (they are needed a whole k-step from now)
             XG2_WAIT8(bn);
             block(X2Int<0>{}, bn, X2Int<2>{});   // ah.bm
             if (STORE) hid_store(P, kcn);  // (the youngest memory operations of the k-step; the pass's last k-step re-stores k-step 0)
+            X2STAMP(6);
             (void)kcn;
             ++cs;
           };

@@ -50,10 +50,12 @@ class JointNetwork(torch.nn.Module):
         audio_frame, text_frame = self._project(audio_frame, text_frame)
         return F_amd.joint_logits(audio_frame, text_frame, self.joint_ln.weight, self.joint_ln.bias)
 
-    # Arithmetic of the fused training step (RNNTModel.forward): "bf16x3" = fp32-ACCURATE results from the bf16 matrix
-    # pipes (include/rnnt_engine.h RNNT_DTYPE_F32_BF16X3: the fp32 route's 1e-4 parity bar, ~1.5x its speed); "fp32" =
-    # exact fp32 products; "bf16" = bf16-rounded operands (BASELINE config 3; not the reference's arithmetic).
-    compute_dtype = "bf16x3"
+    # Arithmetic of the fused training step (RNNTModel.forward): "f16x2" = fp32-CLASS results from the fp16 matrix pipes
+    # (include/rnnt_engine.h RNNT_DTYPE_F32_F16X2: operands scaled by powers of two and split into two fp16 pieces = 22
+    # significant bits, three MFMA products per fp32 product; the fp32 route's 1e-4 parity bar with its measured error class,
+    # ~2.3x its speed); "bf16x3" = the same from six bf16 products of 3-way split operands (24 bits, ~1.5x); "fp32" = exact
+    # fp32 products; "bf16" = bf16-rounded operands (BASELINE config 3; not the reference's arithmetic).
+    compute_dtype = "f16x2"
 
     def fused_loss(self, audio_frame, text_frame, targets, logit_lengths, target_lengths,
                    blank=-1, reduction="mean", **kw):
