@@ -916,16 +916,20 @@ size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
 // and the two log-probs per lattice cell (as the fp32 route's forward).  Tile = 128 consecutive cells; 4 waves = 2 (M) x 2 (N),
 // wave tile 64 cells x 256 columns = 16 accumulator tiles (256 registers); a pass = 512 logits columns, passes run back to
 // back over one linear k-step sequence.  Per k-step ONE barrier, then 3 products x 16 MFMAs:
-//      block 0  ah.bh   + the 8 fragment reads of W's mid plane + A(cs+1): the tanh pieces
-//      block 1  am.bh   + W DMAs 0-3 of k-step cs+1 + A(cs+1): the split pieces;   then the operand loads of k-step cs+2
+//      block 0  ah.bh   + the 8 fragment reads of W's mid plane + A(cs+1): the tanh pieces;   then the operand loads of k-step cs+2
+//      block 1  am.bh   + W DMAs 0-3 of k-step cs+2 + A(cs+1): the split pieces
 //      block 2  ah.bm   + W DMAs 4-7 + A(cs+1): the two ring writes;               then (first pass) the 2 hidden stores
-// (memory operations unconditional and in one fixed order per k-step: every vmcnt is a count).
+// (memory operations unconditional and in one fixed order per k-step — loads, DMAs, stores: every vmcnt is a count).
+// W ring of THREE slots, filled TWO k-steps ahead: with two slots (k_joint_fwd_x3's form) the wait for W at the top of a
+// k-step was 1700 of its 4360 cycles here (stamps, round 4: an LDS-DMA from L2 takes ~3000 cycles under this kernel's load,
+// and a k-step of 48 MFMAs no longer covers it).
 // The accumulators hold 2^14 s_W (logits - bias): the pass end multiplies by 2^-14 / s_W and adds the bias (one fma; the bias
 // cannot ride in the accumulators' initial value here: the padding columns' -1e30 would overflow under the scale).
 // Persistent workgroups, one per CU (83 KiB of LDS), tiles from one atomic counter.  Requires H % 128 == 0, V % 128 == 0.
 // ---------------------------------------------------------------------------------------
 #define XF2_WSLOT 32768
 #define XF2_ASLOT 8192
+#define XF2_NW 3   // W ring slots: the DMAs of k-step cs+2 are issued during k-step cs
 #ifdef RNNT_STAMPS
 // Diagnostic build only (-DRNNT_STAMPS): s_memtime stamps of workgroup 0, wave 0, k-steps 8..23 of its first tile:
 // debug[(step-8)*8 + slot] (tools/exp_x3_stamps.py)
@@ -942,9 +946,9 @@ size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
 #endif
 __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int ntiles)
 {
-    // [0, 64 KiB): W ring;  [64, 80 KiB): A ring;  then: s_den[128], s_part[2][128][2], s_next[2]
+    // [0, 96 KiB): W ring, 3 slots;  [96, 112 KiB): A ring, 2 slots;  then: s_den[128], s_part[2][128][2], s_next[2]
     extern __shared__ __attribute__((aligned(1024))) char s_fw[];
-    float *s_den = (float *)(s_fw + 2 * XF2_WSLOT + 2 * XF2_ASLOT);
+    float *s_den = (float *)(s_fw + XF2_NW * XF2_WSLOT + 2 * XF2_ASLOT);
     float *s_part = s_den + 128;  // [wn][row][max, sum]
     int *s_next = (int *)(s_part + 512);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -958,8 +962,8 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
     const float unscale = X2_INV_SH * a.scales[1];
 
     const int lds0 = (int)(size_t)(lds_vptr)s_fw;
-    const int xa = lds0 + 2 * XF2_WSLOT + (2 * wm) * 2048 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
-    const int xw = lds0 + 2 * XF2_WSLOT + wave * 2048 + 16 * lane;       // A write: M tile `wave` (this lane's own fragment slot)
+    const int xa = lds0 + XF2_NW * XF2_WSLOT + (2 * wm) * 2048 + 16 * lane;  // A read: M tiles 2wm, 2wm+1: [slot][M tile][plane][lane]
+    const int xw = lds0 + XF2_NW * XF2_WSLOT + wave * 2048 + 16 * lane;       // A write: M tile `wave` (this lane's own fragment slot)
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                  // W read: tiles 8wn .. 8wn+7 of each plane
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, npass * KC * XF2_WSLOT, 0x00020000);
     const int wvo = lane * 16;
@@ -1002,10 +1006,18 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         const long ps = a.plane_stride / 8;
         struct Opd { f32x4 e0, e1, p0, p1; };
         struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm; };
-        auto op_load = [&](Opd &o, int kcs) {  // operands of k index kcs (inside a pass)
-            o.e0 = *(const f32x4 *)(ep + 16 * kcs); o.e1 = *(const f32x4 *)(ep + 16 * kcs + 4);
-            o.p0 = *(const f32x4 *)(pp + 16 * kcs); o.p1 = *(const f32x4 *)(pp + 16 * kcs + 4);
+        // operands of k index kcs (inside a pass).  Spelled as asm: hipcc's own vmcnt for a loaded register is the MINIMUM over every
+        // path into the loop (it came out as vmcnt(0) / vmcnt(3) here, draining the W DMAs issued behind these loads); the
+        // kernel counts instead (X2_OPD_LANDED below: nothing reads the registers before it)
+        auto op_load = [&](Opd &o, int kcs) {
+            const float *e = ep + 16 * kcs, *q = pp + 16 * kcs;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.e0) : "v"(e) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(o.e1) : "v"(e) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.p0) : "v"(q) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(o.p1) : "v"(q) : "memory");
         };
+#define X2_OPD_LANDED(o, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(o.e0), "+v"(o.e1), "+v"(o.p0), "+v"(o.p1) :: "memory")
+#define X2_OPD_TIE(o) asm volatile("" : "+v"(o.e0), "+v"(o.e1), "+v"(o.p0), "+v"(o.p1))
         // pieces 0-7: 2^14 tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 2-way split
         // of each pair (hi + residuals, then mid); 16: the two ring writes
         auto prod_piece = [&](Prod &P, const Opd &o, auto off_c, int k) {  // off_c: byte offset of the target A slot in the ring
@@ -1039,9 +1051,9 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             }
         };
         auto hid_store = [&](const Prod &P, int kcs) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; };
-        // piece n (0..7) of this wave's share of W k-step cs -> ring slot cs & 1
-        auto wdma = [&](int cs, int n) {  // raw-buffer form: scalar base and offsets, one constant per-lane offset register
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fw + (cs & 1) * XF2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
+        // piece n (0..7) of this wave's share of W k-step cs -> ring slot `slot`
+        auto wdma = [&](int cs, int slot, int n) {  // raw-buffer form: scalar base and offsets, one constant per-lane offset register
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fw + slot * XF2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
                                                      (cs * 32 + wave * 8 + n) * 1024, 0, 0);
         };
 
@@ -1049,6 +1061,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             for (int kc = 0; kc < KC; ++kc) {
                 Opd o; Prod P;
                 op_load(o, kc);
+                X2_OPD_LANDED(o, 0);
 #pragma unroll
                 for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
                 hid_store(P, kc);
@@ -1066,21 +1079,24 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
         };
-        // pipeline prologue: W of k-step 0 by DMA; A of k-step 0 produced, stored, written to ring slot 0; operands of
+        // pipeline prologue: W of k-steps 0 and 1 by DMA; A of k-step 0 produced, stored, written to ring slot 0; operands of
         // k-step 1 requested
         Opd oset[2];  // operands of k-step cs+1 live in oset[(cs+1) & 1] during k-step cs (KC is even: the k loop is unrolled by 2)
         {
 #pragma unroll
-            for (int n = 0; n < 8; ++n) wdma(0, n);
+            for (int n = 0; n < 8; ++n) wdma(0, 0, n);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) wdma(1, 1, n);
             Opd o; Prod P;
-            op_load(o, 0);
             op_load(oset[1], KC > 1 ? 1 : 0);
+            op_load(o, 0);
+            X2_OPD_LANDED(o, 0);  // (and with it oset[1] and the 16 DMAs)
 #pragma unroll
             for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
             hid_store(P, 0);
         }
 
-        int cs = 0;
+        int cs = 0, wsl = 0;  // k-step (linear over the passes) and its W ring slot (cs % 3)
         // one pass; STORE: the first — the produced planes also go to memory.  Two straight-line instantiations, the first pass
         // outside the loop over the others (a branch between two k loops, like a conditional accumulator re-initialisation
         // inside one, makes hipcc carry the 256 accumulator registers through VGPR phis and spill)
@@ -1092,22 +1108,25 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
           // behind the DMAs waits vmcnt(0))
           auto kstep = [&](auto par_c, const int kc) {
             constexpr int par = decltype(par_c)::value;
-            // W of k-step cs landed (this wave's share).  vmcnt retires in order: behind a k-step's last DMA (block 2) come only
-            // the first pass's 2 hidden stores, which stay in flight (the 4 operand loads sit between the two DMA groups and
-            // retire with them); the first k-step of a pass also follows the previous pass's logits stores
+            // W of k-step cs landed (this wave's share): its DMAs were issued during k-step cs-2.  vmcnt retires in order; behind
+            // them came (first pass) 2 hidden stores, then k-step cs-1's 4 operand loads, 8 DMAs and (first pass) 2 stores.  The
+            // first two k-steps of a pass: their W was waited for before the previous pass's logits stores (pass end below) /
+            // with the tile prologue (vmcnt(0): DMAs of k-steps 0 and 1, operand loads, hidden stores of k-step 0).
             X2STAMP(0);
-            if (kc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (STORE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kc < 2) { if (kc == 0 && STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else if (STORE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             X2STAMP(1);
             x2_lds_barrier();  // publishes W slot and A slot of k-step cs; every wave is past its reads of cs-1
             X2STAMP(2);
-            constexpr int WS = par * XF2_WSLOT, XS = par * XF2_ASLOT, XN = (1 - par) * XF2_ASLOT;
-            const int ws = wb, xs = xa;
-            // the next k-step (past the end: its own, never read) and the one after (operand loads)
-            const int csn = cs + 1 < NS ? cs + 1 : cs, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
-            const Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
-            Opd &onext = oset[par & 1];             // refilled with those of k-step cs+2
+            constexpr int WS = 0, XS = par * XF2_ASLOT, XN = (1 - par) * XF2_ASLOT;
+            const int ws = wb + wsl * XF2_WSLOT, xs = xa;  // (the W slot is a run-time third: one v_add per k-step)
+            // the k-step whose W is requested now (past the end: the last one again, never read), the next k-step of the pass and
+            // the one after (operand loads)
+            const int csn = cs + 2 < NS ? cs + 2 : NS - 1, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
+            const int wsn = wsl == 0 ? 2 : wsl - 1;  // (cs + 2) % 3
+            Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
+            Opd &onext = oset[par & 1];       // refilled with those of k-step cs+2
             Prod P;
             u32x4 af[2][2], bf[8], bn[8];
 #pragma unroll
@@ -1132,33 +1151,43 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                         prod_piece(P, ocur, X2Int<XN>{}, q);
                     }
                     if (BLK == 1) {
-                        if (q & 1) wdma(csn, q >> 1);
+                        if (q & 1) wdma(csn, wsn, q >> 1);
                         prod_piece(P, ocur, X2Int<XN>{}, 8 + q);
                     }
                     if (BLK == 2) {
-                        if (q & 1) wdma(csn, 4 + (q >> 1));
+                        if (q & 1) wdma(csn, wsn, 4 + (q >> 1));
                         if (q == 0) prod_piece(P, ocur, X2Int<XN>{}, 16);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
             X2STAMP(3);
+            // operands of k-step cs+1: requested after block 0 of the previous k-step, in front of its 8 DMAs and (first pass) 2
+            // stores; a pass's first k-step: waited for at the previous pass's end / with the tile prologue
+            if (kc == 0) X2_OPD_TIE(ocur);
+            else if (STORE) X2_OPD_LANDED(ocur, 10);
+            else X2_OPD_LANDED(ocur, 8);
             block(X2Int<0>{}, bf, X2Int<0>{});   // ah.bh
             X2STAMP(4);
+            op_load(onext, kcnn);  // operands of k-step cs+2 (needed a whole k-step from now): in FRONT of the k-step's DMAs
             block(X2Int<1>{}, bf, X2Int<1>{});   // am.bh
             X2STAMP(5);
-            op_load(onext, kcnn);  // operands of k-step cs+2: between the DMA groups (they are needed a whole k-step from now)
             XG2_WAIT8(bn);
             block(X2Int<0>{}, bn, X2Int<2>{});   // ah.bm
             if (STORE) hid_store(P, kcn);  // (the youngest memory operations of the k-step; the pass's last k-step re-stores k-step 0)
             X2STAMP(6);
             (void)kcn;
             ++cs;
+            wsl = wsl == 2 ? 0 : wsl + 1;
           };
           for (int kc0 = 0; kc0 < KC; kc0 += 2) { kstep(X2Int<0>{}, kc0); kstep(X2Int<1>{}, kc0 + 1); }
           // pass complete: unscale, add the bias, store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column
           // groups exist or not for the whole wave.  The row loop is ONE basic block per case; the store address is a scalar
           // row pointer + one 32-bit per-lane offset.
+          // (W of the next pass's first two k-steps — requested during the last two above — lands before the logits stores are
+          // queued behind it: the k-steps' counted waits cannot see past 63 younger operations)
+          if (STORE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           {
             const int cw = 512 * pass + 256 * wn;
             const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
@@ -1266,7 +1295,7 @@ void launch_joint_fwd_x2(const X3Args &a, hipStream_t st)
     static bool attr_set[16] = {false};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-    const int lds = 2 * XF2_WSLOT + 2 * XF2_ASLOT + 128 * 4 + 2 * 128 * 2 * 4 + 16;
+    const int lds = XF2_NW * XF2_WSLOT + 2 * XF2_ASLOT + 128 * 4 + 2 * 128 * 2 * 4 + 16;
     if (dev < 0 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)k_joint_fwd_x2, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (dev >= 0) attr_set[dev] = true;
