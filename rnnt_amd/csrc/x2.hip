@@ -513,10 +513,10 @@ size_t x2_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V /
 //    [2 slots][M tile][plane][lane]; logits requested 4 k-steps ahead (register ring);
 //  * G leaves in WHOLE 128-byte lines (32 x hi | 32 x mid of one cell and chunk = the fragments of two k-steps x two halves x
 //    two planes), read back by the producing wave from its part of the exchange every second k-step: 4 store instructions;
-//  * W: one linear LDS-DMA copy of 32 KiB per k-step into a 2-slot ring (8 DMAs per wave);
+//  * W: one linear LDS-DMA copy of 32 KiB per k-step into a 3-slot ring, two k-steps ahead (8 DMAs per wave);
 //  * per k-step ONE barrier publishes W slot c and exchange slot c; then 3 products x 16 MFMAs:
 //      block 0  ah.bh   + the 8 fragment reads of W's mid plane + production slices 0-7 of G(c+1) (exp2, corrections, split)
-//      block 1  am.bh   + exchange write of G(c+1), W DMAs 0-6 of k-step c+1, (even c) the pair's line reads
+//      block 1  am.bh   + exchange write of G(c+1), W DMAs 0-6 of k-step c+2, (even c) the pair's line reads
 //      block 2  ah.bm   + W DMA 7, (even c) the 4 line stores, the 2 raw logits loads of k-step c+5
 //    (memory operations in ONE fixed order per k-step — DMAs, then stores, then loads — so that every vmcnt is a count).
 // FIRST = false (H > 512: columns 512.., one launch per further 512): G's planes are read back from memory into the exchange
@@ -528,10 +528,11 @@ size_t x2_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V /
 #define XG2_BU 16
 #define XG2_WSLOT 32768   // one k-step of W: 2 planes x 16 tiles x 1 KiB
 #define XG2_XSLOT 8192    // one k-step of G fragments: 4 M tiles x 2 planes x 1 KiB
+#define XG2_NW 3          // W ring slots: the DMAs of k-step c+2 are issued during k-step c (as in k_joint_fwd_x2)
 template <bool FIRST>
 __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
 {
-    // [0, 64 KiB): W ring, 2 slots;  [64, 80 KiB): G exchange, 2 slots.  The epilogue reuses the W ring.
+    // [0, 96 KiB): W ring, 3 slots;  [96, 112 KiB): G exchange, 2 slots.  The epilogue reuses the W ring.
     extern __shared__ __attribute__((aligned(1024))) char s_dh[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
     const int lds0 = (int)(size_t)(lds_vptr)s_dh;
     const int lpiece = lane & 7, lrow = lane >> 3;
     // LDS: [slot = parity][M tile wave][plane][lane slot = row + 32 half]
-    const int xl = lds0 + 2 * XG2_WSLOT + ((lpiece >> 1) & 1) * XG2_XSLOT + wave * 2048 + (lpiece >> 2) * 1024 + 16 * (lrow + 32 * (lpiece & 1));
+    const int xl = lds0 + XG2_NW * XG2_WSLOT + ((lpiece >> 1) & 1) * XG2_XSLOT + wave * 2048 + (lpiece >> 2) * 1024 + 16 * (lrow + 32 * (lpiece & 1));
     const long tile_cell0 = ((long)b * T + t0) * U1 + u0;  // the tile's first cell (exists: t0 < Tb <= T, u0 <= Ub < U1)
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.logits + tile_cell0 * V), 0, (int)((((long)(XG2_BT - 1) * U1 + XG2_BU) * V) * 4), 0x00020000);
@@ -603,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][q][r] = 0.f;
 
-    const int xw = lds0 + 2 * XG2_WSLOT + wave * 2048 + 16 * lane;       // exchange write: [slot][M tile wave][plane][lane]
-    const int xa = lds0 + 2 * XG2_WSLOT + (2 * wm) * 2048 + 16 * lane;   // exchange read: M tiles 2wm, 2wm+1
+    const int xw = lds0 + XG2_NW * XG2_WSLOT + wave * 2048 + 16 * lane;       // exchange write: [slot][M tile wave][plane][lane]
+    const int xa = lds0 + XG2_NW * XG2_WSLOT + (2 * wm) * 2048 + 16 * lane;   // exchange read: M tiles 2wm, 2wm+1
     const int wb = lds0 + (8 * wn) * 1024 + 16 * lane;                   // W read: tiles 8wn .. 8wn+7 of each plane
     // W DMA: wave w copies pieces 8w .. 8w+7 of the k-step's 32 (piece = 1 KiB = one (plane, tile)); raw-buffer form: scalar
     // base (this launch's 512-column pass) and offsets, one constant per-lane offset
@@ -670,32 +671,37 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
 #pragma unroll
         for (int sl = 0; sl < 9; ++sl) produce_slice(P, r, c, sl);
     };
-    auto wdma = [&](int c, int n) {  // piece n (0..7) of this wave's share of W k-step c -> ring slot c & 1
+    auto wdma = [&](int c, int slot, int n) {  // piece n (0..7) of this wave's share of W k-step c -> ring slot `slot`
         const int cc = c < VC ? c : VC - 1;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + (c & 1) * XG2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + slot * XG2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
                                                  (cc * 32 + wave * 8 + n) * 1024, 0, 0);
     };
 
     Raw xr[4];  // raw ring (slot = k-step & 3), 4 k-steps ahead of production
     xload(xr[0], 0); xload(xr[1], 1); xload(xr[2], 2); xload(xr[3], 3);
 #pragma unroll
-    for (int n = 0; n < 8; ++n) wdma(0, n);
+    for (int n = 0; n < 8; ++n) wdma(0, 0, n);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) wdma(1, 1, n);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the in-place stores of the first pair overwrite logits of k-steps 0, 1
     produce(xr[0], 0);
     xload(xr[0], 4);
 
+    int wsl = 0;  // W ring slot of k-step c (c % 3)
     for (int c0 = 0; c0 < VC; c0 += 4) {  // VC % 4 == 0 (V % 128 == 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + j;
-            // W k-step c landed (this wave's share), G fragments of step c written: publish both; every wave is past its reads of
-            // step c-1 (W slot and exchange slot of c+1).  vmcnt retires in order: behind the previous k-step's DMAs come its
-            // (even k-step) 4 line stores and its 2 raw loads.  In-place safety: a pair's line overwrites the logits of its own two
-            // k-steps, both loaded — and waited for by this counter — at least two k-steps before the store is issued.
-            if (FIRST && (j & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // W k-step c landed (this wave's share; requested during k-step c-2), G fragments of step c written: publish both; every
+            // wave is past its reads of step c-1 (W slot of c+2, exchange slot of c+1).  vmcnt retires in order: behind the DMAs of
+            // k-step c-2 come its (even) 4 line stores and 2 raw loads, then k-step c-1's 8 DMAs, (even) 4 line stores and 2 raw
+            // loads: 16 operations whatever c's parity.  In-place safety: a pair's line overwrites the logits of its own two
+            // k-steps, both loaded and consumed (production) before the store is issued.
+            if (FIRST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             x2_lds_barrier();
-            const int ws = wb + (j & 1) * XG2_WSLOT, xs = xa + (j & 1) * XG2_XSLOT;
+            const int ws = wb + wsl * XG2_WSLOT, xs = xa + (j & 1) * XG2_XSLOT;
+            const int wsn = wsl == 0 ? 2 : wsl - 1;  // (c + 2) % 3
             u32x4 af[2][2], bf[8], bn[8];
             // fragment reads: A (4) and the hi plane of W (8)
 #pragma unroll
@@ -735,12 +741,12 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
                     }
                     if (BLK == 1) {
                         if (q == 0 && prod_on) produce_slice(P, rawn, c + 1, 8);
-                        if (q >= 1) wdma(c + 1, q - 1);
+                        if (q >= 1) wdma(c + 2, wsn, q - 1);
                         if (FIRST && q == 2 && !(j & 1) && prod_on) { line_read(ln[0], X2Int<0>{}); line_read(ln[1], X2Int<1>{}); }
                         if (FIRST && q == 4 && !(j & 1) && prod_on) { line_read(ln[2], X2Int<2>{}); line_read(ln[3], X2Int<3>{}); }
                     }
                     if (BLK == 2) {
-                        if (q == 0) wdma(c + 1, 7);
+                        if (q == 0) wdma(c + 2, wsn, 7);
                         if (FIRST && q >= 2 && q <= 5 && !(j & 1)) {
                             if (prod_on) line_store(ln[q - 2 < 0 ? 0 : (q - 2 > 3 ? 3 : q - 2)], q - 2, c);
                             else { u32x4 z = {0u, 0u, 0u, 0u}; __builtin_amdgcn_raw_buffer_store_b128(z, grs, 0x7ffffff0, 0, 0); }  // (never: VC is even; keeps the count)
@@ -755,6 +761,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
             block(X2Int<1>{}, bf, X2Int<1>{});   // am.bh
             XG2_WAIT8(bn);
             block(X2Int<0>{}, bn, X2Int<2>{});   // ah.bm
+            wsl = wsl == 2 ? 0 : wsl + 1;
         }
     }
     // the epilogue's pred rows are requested BEFORE the drain below (they ride out the G stores' acknowledgements with it)
@@ -869,7 +876,7 @@ void launch_dhidden_x2(const X3Args &a, hipStream_t st)
     static bool attr_set[16] = {false};
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-    const int lds = 2 * XG2_WSLOT + 2 * XG2_XSLOT;
+    const int lds = XG2_NW * XG2_WSLOT + 2 * XG2_XSLOT;
     if (dev < 0 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)k_dhidden_x2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void *)k_dhidden_x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
