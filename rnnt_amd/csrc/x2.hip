@@ -208,12 +208,21 @@ struct X2Frag { u32x2 lo[4], hi[4]; };  // 4 tiles: cells 0-3 / 4-7 of a lane's 
                    "+v"(f.hi[2]), "+v"(f.hi[3])                                                                  \
                  :: "memory")
 
-__global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
+// NW = waves per workgroup.  4: one wave per SIMD, wave tile 128 v x 128 h.  8: TWO waves per SIMD (256 registers each), wave
+// tile 128 v x 64 h = 8 accumulator tiles: what one wave waits for — the barrier, a counted vmcnt, the ~80 cycles each of its
+// LDS-DMA issues blocks it — the SIMD's other wave fills with MFMAs.  MEASURED EQUAL (15.5 ms both, cfg2): the kernel is bound by
+// the bytes it stages — 32 KiB per k-step and CU at ~12.6 B/clk/CU (6.8 TB/s over the chip out of L2), the same rate the forward's
+// and dHidden's W streams reach — not by issue stalls.  4 is the default; 8 stays behind RNNT_VARIANT_X2_DW_8W.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
 {
+    constexpr int WN = NW / 2;      // waves along h
+    constexpr int QN = 8 / WN;      // 32-column h tiles per wave (4 or 2)
+    constexpr int ND = 32 / NW;     // DMA pieces per wave and stage (8 or 4)
     extern __shared__ __attribute__((aligned(1024))) char s_ring[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5;
     const int H = a.H, V = a.V;
     const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
@@ -231,26 +240,29 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
     const long nlive = tab[2 * B + 1];
     const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
 
-    f32x16 acc[4][4];
+    f32x16 acc[4][QN];
 #pragma unroll
     for (int qm = 0; qm < 4; ++qm)
 #pragma unroll
-        for (int qn = 0; qn < 4; ++qn)
+        for (int qn = 0; qn < QN; ++qn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
     // db rides the matrix pipe as in k_dw_x3: one more MFMA per plane and k-step against a column SELECTOR of ones, for one
     // (one h block: two) of the wave's M tiles, into a 17th accumulator tile held in VGPRs
-    const bool do_b = hb < 2;  // workgroup-uniform
-    const int bsel0 = n_hblk >= 2 ? (hb & 1) * 2 + wn : wn;
+    // (8 waves: the four wn of h block 0 take the four M tiles of their wm half)
+    const bool do_b = NW == 8 ? hb == 0 : hb < 2;  // workgroup-uniform
+    const int bsel0 = NW == 8 ? wn : (n_hblk >= 2 ? (hb & 1) * 2 + wn : wn);
+    const bool two_b = NW == 4 && n_hblk < 2;  // one h block, 4 waves: each wave takes two tiles, bsel0 and bsel0 + 2
     f32x16 dacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
     const unsigned sel0 = (lane & 31) == 0 ? 0x3c003c00u : 0u, sel1 = (lane & 31) == 1 ? 0x3c003c00u : 0u;  // fp16 ones
 
     if (g_hi > g_lo) {
-        // ---- DMA source of this wave's operand tile
-        const bool is_g = wave < 2;
-        int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
+        // ---- DMA source of this wave's operand tile (8 waves: two waves per operand tile, one plane each)
+        const int otile = NW == 8 ? wave >> 1 : wave;
+        const bool is_g = otile < 2;
+        int col0 = (is_g ? vb : hb) * 256 + 128 * (otile & 1);
         if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
         const char *pbase[2];  // plane p of this wave's operand: base pointer (wave-uniform), row stride in bytes
         long rstride;
@@ -278,17 +290,20 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
         // p = lane&3) reads rows 8(g>>1) + 4sec + q at chunk 4m + 2(g&1) + (p>>1), +8(p&1) bytes, sec = 0,1.
         const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hh = g >> 1;
         const int lds0 = (int)(size_t)(lds_vptr)s_ring;
-        int abase[4][2], bbase[4][2];
+        int abase[4][2], bbase[QN][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int sec = 0; sec < 2; ++sec) {
                 const int row = 8 * hh + 4 * sec + q;
-                const int ch = 4 * m + 2 * (g & 1) + (pp >> 1);
                 const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-                const int fo = 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
-                abase[m][sec] = lds0 + wm * XW2_TILE + fo;
-                bbase[m][sec] = lds0 + (2 + wn) * XW2_TILE + fo;
+                const int ch = 4 * m + 2 * (g & 1) + (pp >> 1);
+                abase[m][sec] = lds0 + wm * XW2_TILE + 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+                if (m < QN) {  // this wave's h tiles: columns 32 QN wn + 32 m of the 256 = operand tile 2 + (col >> 7), tile (col & 127) / 32
+                    const int col = 32 * QN * wn + 32 * m;
+                    const int chb = 4 * ((col & 127) >> 5) + 2 * (g & 1) + (pp >> 1);
+                    bbase[m < QN ? m : 0][sec] = lds0 + (2 + (col >> 7)) * XW2_TILE + 256 * row + 16 * (chb ^ swz) + 8 * (pp & 1);
+                }
             }
         int sbase[2][2];  // db: fragment bases of the M tile(s) this wave sums (bsel0, and bsel0 + 2 with one h block)
 #pragma unroll
@@ -311,17 +326,23 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
             for (int p = 0; p < 2; ++p)
                 rs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (ks + XW2_NST - 1) * XW2_ROWS) * rstride), 0,
                                                           (int)(XW2_ROWS * rstride), 0x00020000);
-            auto dma_piece = [&](auto n_c) {  // piece n of stage ks+2 -> ring stage DST: plane n>>2, rows 4(n&3)..
-                constexpr int n = decltype(n_c)::value, p = n >> 2, i = n & 3;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + wave * XW2_TILE + DST * XW2_STAGE + p * XW2_PLANE + 1024 * i),
-                                                         16, soff[i], 0, 0, 0);
+            auto dma_piece = [&](auto n_c) {  // piece n of this wave's share of stage ks+NST-1 -> ring stage DST: plane n>>2 (8 waves: wave & 1), rows 4(n&3)..
+                constexpr int n = decltype(n_c)::value, i = n & 3;
+                if (NW == 8) {
+                    if (wave & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[1], (lds_vptr)(s_ring + otile * XW2_TILE + DST * XW2_STAGE + XW2_PLANE + 1024 * i), 16, soff[i], 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[0], (lds_vptr)(s_ring + otile * XW2_TILE + DST * XW2_STAGE + 1024 * i), 16, soff[i], 0, 0, 0);
+                } else {
+                    constexpr int p = (n >> 2) & 1;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + otile * XW2_TILE + DST * XW2_STAGE + p * XW2_PLANE + 1024 * i),
+                                                             16, soff[i], 0, 0, 0);
+                }
             };
             // 8 transposed reads of plane P of the A / B operand (inline asm: hipcc guards every LDS read it can see behind
             // an LDS-DMA with vmcnt(0)); results are used only after X2_LANDED named them
-            auto reads = [&](X2Frag &f, const int (&base)[4][2], auto p_c) {
+            auto reads = [&](X2Frag &f, const auto &base, auto p_c, auto nt_c) {
                 constexpr int off = ST * XW2_STAGE + decltype(p_c)::value * XW2_PLANE;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < decltype(nt_c)::value; ++m) {
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo[m]) : "v"(base[m][0]), "n"(off));
                     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi[m]) : "v"(base[m][1]), "n"(off));
                 }
@@ -329,18 +350,18 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
             // 16 MFMAs of one product with DMA pieces N0 .. N0+CNT-1 threaded through them
             auto product = [&](const X2Frag &fa_, const X2Frag &fb_, auto n0_c, auto cnt_c) {
                 constexpr int N0 = decltype(n0_c)::value, CNT = decltype(cnt_c)::value;
-                u32x4 fa[4], fb[4];
+                u32x4 fa[4], fb[QN];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     fa[m] = u32x4{fa_.lo[m][0], fa_.lo[m][1], fa_.hi[m][0], fa_.hi[m][1]};
-                    fb[m] = u32x4{fb_.lo[m][0], fb_.lo[m][1], fb_.hi[m][0], fb_.hi[m][1]};
+                    if (m < QN) fb[m < QN ? m : 0] = u32x4{fb_.lo[m][0], fb_.lo[m][1], fb_.hi[m][0], fb_.hi[m][1]};
                 }
 #pragma unroll
                 for (int qm = 0; qm < 4; ++qm) {
 #pragma unroll
-                    for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x2_mfma(fa[qm], fb[qn], acc[qm][qn]);
-                    if (qm == 0) dma_piece(X2Int<N0>{});
-                    if (qm == 1) dma_piece(X2Int<N0 + 1>{});
+                    for (int qn = 0; qn < QN; ++qn) acc[qm][qn] = x2_mfma(fa[qm], fb[qn], acc[qm][qn]);
+                    if (qm == 0 && CNT >= 1) dma_piece(X2Int<N0>{});
+                    if (qm == 1 && CNT >= 2) dma_piece(X2Int<N0 + (CNT >= 2 ? 1 : 0)>{});
                     if (qm == 3 && CNT == 3) dma_piece(X2Int<N0 + (CNT == 3 ? 2 : 0)>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -361,38 +382,40 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
             };
             // stage ks landed (the 8 (NST - 2) younger pieces of the stages after it may still fly); every wave is past its reads of
             // stage ks-1, whose ring stage the DMAs below refill
-            if (XW2_NST == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (ND * (XW2_NST - 2) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ND * (XW2_NST - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             x2_lds_barrier();
             X2Frag Ah, Bh, Am, Bm;
             u32x2 dl[2], dh[2];
-            reads(Ah, abase, X2Int<0>{});
-            reads(Bh, bbase, X2Int<0>{});
-            reads(Am, abase, X2Int<1>{});
+            reads(Ah, abase, X2Int<0>{}, X2Int<4>{});
+            reads(Bh, bbase, X2Int<0>{}, X2Int<QN>{});
+            reads(Am, abase, X2Int<1>{}, X2Int<4>{});
             X2_LANDED(Ah, 8);
             X2_LANDED(Bh, 8);
-            product(Ah, Bh, X2Int<0>{}, X2Int<3>{});
-            reads(Bm, bbase, X2Int<1>{});
-            X2_LANDED(Am, 8);
-            product(Am, Bh, X2Int<3>{}, X2Int<3>{});
+            // DMA pieces of the k-step: 3 + 3 + 2 (8 waves: 2 + 1 + 1)
+            product(Ah, Bh, X2Int<0>{}, X2Int<(NW == 8 ? 2 : 3)>{});
+            reads(Bm, bbase, X2Int<1>{}, X2Int<QN>{});
+            if (QN == 4) X2_LANDED(Am, 8); else X2_LANDED(Am, 4);
+            product(Am, Bh, X2Int<(NW == 8 ? 2 : 3)>{}, X2Int<(NW == 8 ? 1 : 3)>{});
             X2_LANDED(Bm, 0);
             if (do_b) { bias_read(dl[0], dh[0], X2Int<0>{}, 0); bias_read(dl[1], dh[1], X2Int<1>{}, 0); }
-            product(Ah, Bm, X2Int<6>{}, X2Int<2>{});
+            product(Ah, Bm, X2Int<(NW == 8 ? 3 : 6)>{}, X2Int<(NW == 8 ? 1 : 2)>{});
             if (do_b) {
                 bias_mfma(dl[0], dh[0], dacc, 0); bias_mfma(dl[1], dh[1], dacc, 0);
-                if (n_hblk < 2) {  // one h block: the wave's second tile (column 1 of the selector product), H <= 256 only
+                if (two_b) {  // one h block: the wave's second tile (column 1 of the selector product), H <= 256 only
                     bias_read(dl[0], dh[0], X2Int<0>{}, 1); bias_read(dl[1], dh[1], X2Int<1>{}, 1);
                     bias_mfma(dl[0], dh[0], dacc, 1); bias_mfma(dl[1], dh[1], dacc, 1);
                 }
             }
         };
-        auto dma_stage = [&](long ks, int st) {  // pipeline prologue: all 8 pieces of stage ks
+        auto dma_stage = [&](long ks, int st) {  // pipeline prologue: this wave's pieces of stage ks
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const int p = n >> 2, i = n & 3;
+            for (int n = 0; n < ND; ++n) {
+                const int p = NW == 8 ? (wave & 1) : n >> 2, i = n & 3;
                 const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                     (void *)(pbase[p] + (row_first + ks * XW2_ROWS) * rstride), 0, (int)(XW2_ROWS * rstride), 0x00020000);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(s_ring + wave * XW2_TILE + st * XW2_STAGE + p * XW2_PLANE + 1024 * i),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(s_ring + otile * XW2_TILE + st * XW2_STAGE + p * XW2_PLANE + 1024 * i),
                                                          16, soff[i], 0, 0, 0);
             }
         };
@@ -428,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
 
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r of tile
     // (qm,qn): v = v0 + 32qm + (r&3) + 8(r>>2) + 4half, h = h0 + 32qn + (lane&31).
-    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
+    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 32 * QN;
     float *sw = a.slab_w + (long)split * V * H;
     const float rw = a.dw_rescale, rb = a.db_rescale;
 #pragma unroll
@@ -438,13 +461,13 @@ __global__ __launch_bounds__(256, 1) void k_dw_x2(X3Args a)
             const int v = v0 + 32 * qm + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (v < V) {
 #pragma unroll
-                for (int qn = 0; qn < 4; ++qn) {
+                for (int qn = 0; qn < QN; ++qn) {
                     const int h = h0 + 32 * qn + (lane & 31);
                     if (h < H) sw[(long)v * H + h] = acc[qm][qn][r] * rw;
                 }
             }
         }
-    if (do_b && (lane & 31) < (n_hblk >= 2 ? 1 : 2)) {  // column k of the selector products: lanes k / 32+k store
+    if (do_b && (lane & 31) < (two_b ? 2 : 1)) {  // column k of the selector products: lanes k / 32+k store
         const int m = bsel0 + 2 * (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -462,10 +485,12 @@ void launch_dw_x2(const X3Args &a, hipStream_t st)
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
     if (dev < 0 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void *)k_dw_x2, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
+        (void)hipFuncSetAttribute((const void *)k_dw_x2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
+        (void)hipFuncSetAttribute((const void *)k_dw_x2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
         if (dev >= 0) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_dw_x2, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
+    if (a.flags & RNNT_VARIANT_X2_DW_8W) hipLaunchKernelGGL(k_dw_x2<8>, dim3(tiles * a.n_split), dim3(512), 4 * XW2_TILE, st, a);
+    else hipLaunchKernelGGL(k_dw_x2<4>, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
 }
 
 #define XG2_WAIT8(b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) :: "memory")

@@ -24,7 +24,7 @@ def amd():
     return rnnt_amd
 
 
-@pytest.mark.parametrize("variant", ["dw_only", "dw_dhidden", "all"])
+@pytest.mark.parametrize("variant", ["dw_only", "dw_dhidden", "all", "dw_8w"])
 @pytest.mark.parametrize("shape", [(2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024), (2, 13, 20, 1024, 256),
                                    (3, 21, 9, 640, 128), (2, 130, 50, 512, 256)])
 def test_x2_kernels_in_isolation(amd, variant, shape):
@@ -32,7 +32,8 @@ def test_x2_kernels_in_isolation(amd, variant, shape):
     / k_x2_split_g in between), with _FWD alone k_dhidden_x2 + k_dw_x2, without a variant all three — each against the fp64
     oracle at the fp32 tolerances."""
     e = amd.engine
-    var = {"dw_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH, "dw_dhidden": e.VARIANT_X3_FP32_FWD, "all": 0}[variant]
+    var = {"dw_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH, "dw_dhidden": e.VARIANT_X3_FP32_FWD, "all": 0,
+           "dw_8w": e.VARIANT_X2_DW_8W}[variant]
     B, T, U, H, V = shape
     d = make_inputs(B, T, U, H, V, seed=sum(shape))
     g = _dev(d)
