@@ -407,6 +407,12 @@ def main():
                            "flops_per_launch": 2.0 * H * V * cells1, "ms_per_launch": gemms[dom]}
         if args.dtype == "f16x2":
             out["roofline"]["peak_note"] = "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 products per fp32 product (fp32-equivalent flops)"
+            # the other roofline of this route's kernels: algorithmic HBM bytes per cell (rnnt_amd/csrc/x2.hip: two fp16 planes per
+            # operand; fwd 4H + 4V, dHidden 4V + 4V, dW 4V + 4H) over the same launch time
+            per_cell = {"joint_fwd_gemm": 4 * H + 4 * V, "dhidden_gemm": 8 * V, "dw_gemm": 4 * V + 4 * H}
+            gbs = per_cell[dom] * cells1 / (gemms[dom] * 1e-3) / 1e9
+            out["roofline"]["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                      "bytes_per_launch": per_cell[dom] * cells1}
         if args.dtype == "bf16x3":
             out["roofline"]["peak_note"] = "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 products per fp32 product (fp32-equivalent flops)"
         if args.dtype == "bf16":

@@ -28,6 +28,21 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((address_space(3))) void *lds_vptr;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Diagnostic build only (-DRNNT_STAMPS): workgroup 0 stamps the core clock counter and the 100 MHz reference at its start and
+// end into debug[SLOT..] (a buffer nothing else reads): the clock this launch ran at (tools/exp_x3_clock.py).
+#ifdef RNNT_STAMPS
+#define X2_CLOCK_STAMP(SLOT)                                                                                               \
+    do {                                                                                                                   \
+        if (a.debug && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {                        \
+            unsigned long long t_, r_;                                                                                     \
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");      \
+            a.debug[SLOT] = t_; a.debug[(SLOT) + 1] = r_;                                                                  \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define X2_CLOCK_STAMP(SLOT) do {} while (0)
+#endif
+
 #define X2_SH 16384.0f          // scale of the hidden operand (|tanh| <= 1)
 #define X2_INV_SH (1.0f / 16384.0f)
 #define X2_F16_MAX 65504.0f
@@ -239,6 +254,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
     const int B = a.B;
     const long nlive = tab[2 * B + 1];
     const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+    X2_CLOCK_STAMP(128 + 104);
 
     f32x16 acc[4][QN];
 #pragma unroll
@@ -451,6 +467,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
 
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r of tile
     // (qm,qn): v = v0 + 32qm + (r&3) + 8(r>>2) + 4half, h = h0 + 32qn + (lane&31).
+    X2_CLOCK_STAMP(128 + 106);
     const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 32 * QN;
     float *sw = a.slab_w + (long)split * V * H;
     const float rw = a.dw_rescale, rb = a.db_rescale;
@@ -569,6 +586,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
     len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub);
     const int t0 = tt * XG2_BT, u0 = ub * XG2_BU;
     const int VC = V / 16;
+    if (FIRST) X2_CLOCK_STAMP(128 + 108);  // (one tile of ~0.1 ms: 1e-4 resolution at the 100 MHz reference)
 
     // ---- producer role: M tile `wave`, row i = cell (pt, pu)
     const int prow = wave * 32 + i;
@@ -888,6 +906,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
             }
         }
     }
+    if (FIRST) X2_CLOCK_STAMP(128 + 110);
 }
 
 bool x2_dhidden_ok(int U1, int H, int V)
@@ -1000,6 +1019,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, npass * KC * XF2_WSLOT, 0x00020000);
     const int wvo = lane * 16;
 
+    X2_CLOCK_STAMP(128 + 100);
     if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
     __syncthreads();
     int tile = s_next[0];
@@ -1318,6 +1338,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         }
         tile = next;
     }
+    X2_CLOCK_STAMP(128 + 102);
 }
 
 bool x2_fwd_ok(int U1, int H, int V) { return H % 128 == 0 && V % 128 == 0 && (long)128 * H * 2 < 0x7fffffffL; }

@@ -13,7 +13,7 @@ def measure():
     B, T, U, H, V = 32, 1000, 200, 512, 1024
     enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
     outs = engine.alloc_fused_outputs(enc, pred, W)
-    run = lambda st: engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, stage=st, dtype="bf16x3")
+    run = lambda st: engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, stage=st, dtype=os.environ.get("STAMP_DTYPE", "bf16x3"))
     for s in range(8): run(s)
     dbg = torch.zeros(512, dtype=torch.int64, device="cuda")
     out = []
@@ -40,6 +40,9 @@ if __name__ == "__main__":
         print(measure(), flush=True)
         sys.exit(0)
     for e in sys.argv[1:]:
-        env = dict(os.environ, RNNT_ENGINE_LIB=os.path.join(ROOT, "build_variants", "x3", f"lib_stamps_{e}.so"))
+        # <exp>: an X3_EXP variant of tools/build_x3_stamp_variants.sh; "x2": tools/build_x2_stamps.sh's library on the f16x2 route
+        env = dict(os.environ, RNNT_ENGINE_LIB=os.path.join(ROOT, "build_variants", "x3", "lib_x2_stamps.so" if e == "x2" else f"lib_stamps_{e}.so"))
+        if e == "x2":
+            env["STAMP_DTYPE"] = "f16x2"
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=300)
         print(f"X3_EXP={e:>5s}  {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else 'FAILED ' + r.stderr[-300:]}", flush=True)
