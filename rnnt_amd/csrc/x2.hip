@@ -1248,45 +1248,49 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             const f32x4 b1 = cw + 128 + 4 * i < V ? *(const f32x4 *)(a.bias + cw + 128 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
             auto epilogue = [&](auto both_c) {
                 constexpr bool BOTH = decltype(both_c)::value != 0;
+                // one row slot: unscale + bias, store, (max, sum exp) over this wave's 128 / 256 columns of the pass (8 values per
+                // lane, then the 32 lanes of the half on the DPP crossbar), running statistics of the row (lanes 31 / 63)
+                auto slot = [&](int mt, int r) {
+                    // accumulator reads spelled as (volatile) asm: they stay here — left to hipcc, all 256 v_accvgpr_read are
+                    // hoisted in front of the first store and spilled
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float x0, x1;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[mt][q][r]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[mt][4 + q][r]));
+                        o0[q] = fmaf(x0, unscale, b0[q]); o1[q] = fmaf(x1, unscale, b1[q]);
+                    }
+                    char *rowp = tile_base + (long)(32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2)) * V * 4;  // wave-uniform
+                    __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
+                    if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
+                    float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
+                    if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                    const float M = half_max_dpp(m8, half);
+                    const float nm2 = -M * RNNT_LOG2E;
+                    float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                              (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                    if (BOTH)
+                        e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                             (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                    const float S_ = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
+                    if (i == 31) {
+                        float *sp = s_part + (wn * 128 + 32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
+                        const float m_o = sp[0], s_o = sp[1];
+                        const float mn = fmaxf(m_o, M);
+                        sp[0] = mn;
+                        sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                    }
+                };
+                // TWO row slots at a time: with one wave per SIMD a slot is a chain of dependent latencies (accumulator reads, the
+                // two DPP reductions, exp2, the LDS update); the second slot's chain fills the first one's gaps
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // accumulator reads spelled as (volatile) asm: they stay here, one row slot at a time — left to
-                        // hipcc, all 256 v_accvgpr_read are hoisted in front of the first store and spilled
-                        f32x4 o0, o1;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float x0, x1;
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x0) : "a"(acc[mt][q][r]));
-                            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x1) : "a"(acc[mt][4 + q][r]));
-                            o0[q] = fmaf(x0, unscale, b0[q]); o1[q] = fmaf(x1, unscale, b1[q]);
-                        }
-                        char *rowp = tile_base + (long)(32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2)) * V * 4;  // wave-uniform
-                        __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
-                        if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
-                        {
-                            // the row slot's (max, sum exp) over this wave's 128 / 256 columns of the pass: 8 values per
-                            // lane, then the 32 lanes of the half on the DPP crossbar
-                            float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
-                            if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
-                            const float M = half_max_dpp(m8, half);
-                            const float nm2 = -M * RNNT_LOG2E;
-                            float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
-                                      (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
-                            if (BOTH)
-                                e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
-                                     (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
-                            const float S_ = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
-                            if (i == 31) {
-                                float *sp = s_part + (wn * 128 + 32 * (2 * wm + mt) + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
-                                const float m_o = sp[0], s_o = sp[1];
-                                const float mn = fmaxf(m_o, M);
-                                sp[0] = mn;
-                                sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
+                    for (int r = 0; r < 16; r += 2) {
+                        slot(mt, r);
+                        slot(mt, r + 1);
+                        __builtin_amdgcn_sched_barrier(0);  // (a pair at a time: see the accumulator reads)
                     }
             };
             if (cw + 128 < V) epilogue(X2Int<1>{});
