@@ -53,10 +53,11 @@ def test_committed_bf16_bench_line(rnd):
         assert d["steps"] == 20
 
 
-def test_committed_round4_default_bench_line():
-    """The shipped default (bf16x3 arithmetic, fp32-accurate): the line carries the exact-fp32 route timed in the same run, the
-    MFMA-busy figure replayed from the committed SQ counter pass, and names its ranks by transport."""
-    d = _line("r04_bench_default.json")
+def test_committed_round4_bf16x3_bench_line():
+    """Round 4's first default (bf16x3 arithmetic, fp32-accurate; kept as profiles/r04_bf16x3_bench_default.json): the line
+    carries the exact-fp32 route timed in the same run, the MFMA-busy figure replayed from the committed SQ counter pass, and
+    names its ranks by transport."""
+    d = _line("r04_bf16x3_bench_default.json")
     _check(d, "f32")
     r = d["roofline"]
     assert r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 6.0) < 1e-6 and r["traffic"] > 0
@@ -67,8 +68,32 @@ def test_committed_round4_default_bench_line():
     assert abs(e["loss"] - d["loss"]) <= 1e-4 * abs(d["loss"])  # the two arithmetic forms agree on the same inputs
     assert d["rccl_ranks"] == 0 and "dist_ranks" not in d and d["steps"] == 20
     assert d["parity"]["loss_rel_err"] < 1e-4 and d["parity"]["grad_rel_err"] < 1e-4
-    c4 = _line("r04_cfg4_bf16x3_bench.json")  # config 4 on the shipped default route: a kept record
+    c4 = _line("r04_cfg4_bf16x3_bench.json")  # config 4 on that route: a kept record
     assert "cfg4" in c4["config"]["workload"] and "bf16x3" in c4["config"]["workload"] and c4["ms_per_step"] > 0
+
+
+def test_committed_round4_default_bench_line():
+    """The shipped default (f16x2 arithmetic: three fp16 products of scaled, 2-way split operands, fp32-class): the line carries
+    the exact-fp32 route AND the bf16x3 route timed in the same run on the same inputs (all three agree on the loss), both
+    rooflines of the dominant kernel, the replayed PMC figures, the CPU baseline."""
+    d = _line("r04_bench_default.json")
+    _check(d, "f32")
+    assert "f16x2" in d["config"]["workload"] and "v_mfma_f32_32x32x16_f16" in d["arith"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 3.0) < 1e-6 and r["traffic"] > 0
+    assert 0.2 < r["mfma_busy"] < 1.0 and r["mfma_busy_source"]["replayed"] is True
+    assert os.path.exists(os.path.join(ROOT, r["mfma_busy_source"]["file"])) and os.path.exists(os.path.join(ROOT, r["traffic_source"]["file"]))
+    assert 0.0 < r["hbm"]["frac"] < 1.0 and r["hbm"]["peak"] == 8000.0
+    e, x3 = d["exact_fp32"], d["bf16x3"]
+    assert e["peak"] == 157.3 and e["ms_per_step"] > x3["ms_per_step"] > d["ms_per_step"]
+    for other in (e, x3):  # the three arithmetic forms agree on the same inputs
+        assert abs(other["loss"] - d["loss"]) <= 1e-4 * abs(d["loss"])
+    assert d["rccl_ranks"] == 0 and "dist_ranks" not in d and d["steps"] == 20
+    assert d["parity"]["loss_rel_err"] < 1e-4 and d["parity"]["grad_rel_err"] < 1e-4
+    assert d["ms_per_step"] < 85.0  # round-3 verdict item 1's target for config 2
+    for name in ("cfg4", "cfg5"):  # configs 4 and 5 on the shipped default route: kept records
+        c = _line(f"r04_{name}_f16x2_bench.json")
+        assert name in c["config"]["workload"] and "f16x2" in c["config"]["workload"] and c["ms_per_step"] > 0
 
 
 def test_bench_refuses_to_run_fewer_gpus_than_asked():

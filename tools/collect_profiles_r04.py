@@ -15,7 +15,7 @@ def cp(a, b):
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
 B, T, U, H, V = 32, 1000, 200, 512, 1024
 cells = B * T * (U + 1)
-cp("r04.default.json", "r04_bench_default.json")
+cp("r04.default.json", "r04_bf16x3_bench_default.json")
 for a, b in (("fp32", "fp32"), ("bf16", "bf16"), ("bf16x3.permuted", "bf16x3_permuted_enc"), ("cfg5", "cfg5_bf16x3"), ("cfg4", "cfg4_bf16x3"),
              ("ref1024.bf16x3", "ref1024_bf16x3")):
     cp(f"r04.{a}.json", f"r04_{b}_bench.json")
