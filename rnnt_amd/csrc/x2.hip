@@ -1058,18 +1058,16 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         const long ps = a.plane_stride / 8;
         struct Opd { f32x4 e0, e1, p0, p1; };
         struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm; };
-        // operands of k index kcs (inside a pass).  Spelled as asm: hipcc's own vmcnt for a loaded register is the MINIMUM over every
-        // path into the loop (it came out as vmcnt(0) / vmcnt(3) here, draining the W DMAs issued behind these loads); the
-        // kernel counts instead (X2_OPD_LANDED below: nothing reads the registers before it)
+        // operands of k index kcs (inside a pass): plain loads, hipcc keeps their vmcnt.  (Its count for a loop-carried register is
+        // the MINIMUM over every path into the loop — vmcnt(3) / vmcnt(0) in front of block 0 here, which also waits for the W
+        // DMAs issued behind these loads a k-step ago.  Spelling the loads as asm with a counted wait was tried and is WRONG: the
+        // loaded registers are loop-carried, and the copies hipcc places on the loop's back edge read them before the data has
+        // landed — intermittently different results at full size, tools/dbg_x2_loss.py.)
         auto op_load = [&](Opd &o, int kcs) {
             const float *e = ep + 16 * kcs, *q = pp + 16 * kcs;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.e0) : "v"(e) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(o.e1) : "v"(e) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.p0) : "v"(q) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(o.p1) : "v"(q) : "memory");
+            o.e0 = *(const f32x4 *)e; o.e1 = *(const f32x4 *)(e + 4);
+            o.p0 = *(const f32x4 *)q; o.p1 = *(const f32x4 *)(q + 4);
         };
-#define X2_OPD_LANDED(o, N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(o.e0), "+v"(o.e1), "+v"(o.p0), "+v"(o.p1) :: "memory")
-#define X2_OPD_TIE(o) asm volatile("" : "+v"(o.e0), "+v"(o.e1), "+v"(o.p0), "+v"(o.p1))
         // pieces 0-7: 2^14 tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 2-way split
         // of each pair (hi + residuals, then mid); 16: the two ring writes
         auto prod_piece = [&](Prod &P, const Opd &o, auto off_c, int k) {  // off_c: byte offset of the target A slot in the ring
@@ -1113,7 +1111,6 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             for (int kc = 0; kc < KC; ++kc) {
                 Opd o; Prod P;
                 op_load(o, kc);
-                X2_OPD_LANDED(o, 0);
 #pragma unroll
                 for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
                 hid_store(P, kc);
@@ -1142,7 +1139,6 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             Opd o; Prod P;
             op_load(oset[1], KC > 1 ? 1 : 0);
             op_load(o, 0);
-            X2_OPD_LANDED(o, 0);  // (and with it oset[1] and the 16 DMAs)
 #pragma unroll
             for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
             hid_store(P, 0);
@@ -1177,7 +1173,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             // the one after (operand loads)
             const int csn = cs + 2 < NS ? cs + 2 : NS - 1, kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
             const int wsn = wsl == 0 ? 2 : wsl - 1;  // (cs + 2) % 3
-            Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
+            const Opd &ocur = oset[(par + 1) & 1];  // operands of k-step cs+1 (requested during the previous k-step)
             Opd &onext = oset[par & 1];       // refilled with those of k-step cs+2
             Prod P;
             u32x4 af[2][2], bf[8], bn[8];
@@ -1214,11 +1210,6 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                 }
             };
             X2STAMP(3);
-            // operands of k-step cs+1: requested after block 0 of the previous k-step, in front of its 8 DMAs and (first pass) 2
-            // stores; a pass's first k-step: waited for at the previous pass's end / with the tile prologue
-            if (kc == 0) X2_OPD_TIE(ocur);
-            else if (STORE) X2_OPD_LANDED(ocur, 10);
-            else X2_OPD_LANDED(ocur, 8);
             block(X2Int<0>{}, bf, X2Int<0>{});   // ah.bh
             X2STAMP(4);
             op_load(onext, kcnn);  // operands of k-step cs+2 (needed a whole k-step from now): in FRONT of the k-step's DMAs

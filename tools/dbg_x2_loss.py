@@ -1,0 +1,25 @@
+"""cfg2 (full size) on the f16x2 route, repeated: loss and gradient checksums of every call against the fp32-MFMA route's —
+a race shows up as a run-to-run difference.   python3 tools/dbg_x2_loss.py [reps]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import synth, CONFIGS
+from rnnt_amd import engine
+B, T, U, H, V = CONFIGS[os.environ.get("CFG", "cfg2")]
+enc, pred, W, bias, targets, ll, tl = synth(B, T, U, H, V, 1, "cuda")
+outs = engine.alloc_fused_outputs(enc, pred, W)
+def run(dt, var=0):
+    engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, dtype=dt, variant=var)
+    torch.cuda.synchronize()
+    return [float(outs[0].double().sum())] + [float(o.double().abs().sum()) for o in outs[1:]]
+ref = run("fp32")
+print("fp32 ", ["%.9g" % v for v in ref])
+bad = 0
+for name, var in (("f16x2", 0), ("f16x2 fwd=fp32", engine.VARIANT_X3_FP32_FWD), ("f16x2 fwd,dh=fp32", engine.VARIANT_X3_FP32_FWD | engine.VARIANT_X3_FP32_DH)):
+    for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+        r = run("f16x2", var)
+        rel = [abs(a - b) / abs(b) for a, b in zip(r, ref)]
+        flag = "" if max(rel) < 2e-6 else "   <-- DIFFERS"
+        bad += bool(flag)
+        print(f"{name:18s}", ["%.9g" % v for v in r], "rel", ["%.1e" % v for v in rel], flag, flush=True)
+print("bad runs:", bad)
