@@ -127,7 +127,7 @@ void layout(int B, int T, int U1, int H, int V, int dtype, rnnt_engine_ws_layout
     {   // + the dW live-row table (bf16 routes) / live-granule list (fp32 route), whichever is larger
         const size_t tab = (2 * (size_t)B + 2) * 8, lst = (bf || x3) ? 0 : dw_list_bytes(B, T, U1, 16);
         L->counters = o; o += 1024 + align_up(tab > lst ? tab : lst);
-        if (bf) o += align_up((size_t)L->n_split * 64);  // k_dw_bf16's progress words, behind the table
+        if (bf || x2) o += align_up((size_t)L->n_split * 64);  // k_dw_bf16's / k_dw_x2's progress words, behind the table
     }
     L->total = o;
     if (x3) {  // fp32 hidden + fp32 W pack of the stages that can run on the fp32 route's kernels (RNNT_VARIANT_X3_FP32_*):
@@ -292,6 +292,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
             h.g_scale = ldexpf(1.0f, k);
             h.dw_rescale = 1.0f / (h.g_scale * 16384.0f); h.db_rescale = 1.0f / h.g_scale;
             h.scales = (const float *)(ws + L.counters + 640);
+            h.dw_prog = x2 ? (int *)(ws + L.counters + 1024 + align_up((2 * (size_t)B + 2) * 8)) : nullptr;
         }
         h.logits = logits; h.g_lo = (unsigned short *)(ws + L.g_lo); h.coef = coef;
         h.targets = targets; h.logit_lens = logit_lens; h.target_lens = target_lens;

@@ -153,6 +153,7 @@ struct X3Args {
     float g_scale;              // power of two with |g_scale G| <= 2^13 (from grad_scale)
     float dw_rescale, db_rescale;  // 1 / (g_scale 2^14), 1 / g_scale
     const float *scales;        // device: {s_W, 1 / s_W} (k_x2_wscale, every call)
+    int *dw_prog;               // [n_split][16] progress words of k_dw_x2's tiles (zeroed by its launcher), or NULL
 };
 bool x3_fwd_ok(int U1, int H, int V);      // the bf16x3 forward kernel covers this shape (else: the fp32 route's)
 bool x3_dhidden_ok(int U1, int H, int V);  // likewise k_dhidden_x3

@@ -436,6 +436,33 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
             }
         };
 
+        // Soft lockstep of the tiles of a split (k_dw_bf16's, round 3).  They walk the same k-steps and share every operand byte
+        // through their XCD's L2 (G between the h blocks, hidden between the v blocks); nothing else holds them together, and at
+        // this kernel's pace a tile that falls behind finds its lines evicted and becomes its own HBM stream — counted without
+        // it: 83 GB fetched for 39.5 GB of operands (profiles/r04_f16x2_hbm_traffic_pmc.txt, first pass).  Every NST k-steps a
+        // tile publishes its k-step count and looks at its right-hand neighbour's in the ring of the split's tiles (one coherent
+        // scalar load, issued a look before its value is used); a tile more than DW_LAG k-steps ahead of that neighbour naps.
+        // Bounded: after DW_NAPS naps without the neighbour catching up (a partner that is not resident) the tile stops looking,
+        // so every wave reaches the end whatever the others do.
+        constexpr int DW_LAG = 6, DW_NAPS = 256;
+        int *prog = a.dw_prog ? a.dw_prog + split * 16 : nullptr;
+        bool sync_on = prog != nullptr && tiles > 1 && tiles <= 16;
+        const int *nb = prog ? prog + (tile + 1 < tiles ? tile + 1 : 0) : nullptr;  // the neighbour's word
+        int nb_at = 0x7fffffff;  // the neighbour's k-step count as of the last look
+        int done = 0;            // k-steps behind this workgroup, over all ranges
+        auto lockstep = [&](int mine) {  // (wave-uniform)
+            // the value requested at the previous look has long landed (lgkmcnt(0) of the barriers since)
+            int naps = 0;
+            while (sync_on && nb_at + DW_LAG + XW2_NST < mine) {  // (+NST: the value is one look old)
+                if (++naps > DW_NAPS) { sync_on = false; break; }
+                __builtin_amdgcn_s_sleep(4);
+                asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(nb_at) : "s"(nb) : "memory");
+            }
+            if (sync_on) {
+                if (tid == 0) __hip_atomic_store(prog + tile, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (one more outstanding store only makes the counted waits stricter)
+                asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(nb_at) : "s"(nb) : "memory");  // used at the next look
+            }
+        };
         int ub = 0;
         while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;
         for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
@@ -450,6 +477,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
             if (XW2_NST == 4) dma_stage(2, 2);
             for (long ks = 0;;) {  // the ring stage of a k-step is ks % NST: unrolled by NST
                 if (ks >= nks) break;
+                lockstep(done + (int)ks);
                 kstep(X2Int<0>{}, ks, dacc); ++ks;
                 if (ks >= nks) break;
                 kstep(X2Int<1>{}, ks, dacc); ++ks;
@@ -497,6 +525,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
 void launch_dw_x2(const X3Args &a, hipStream_t st)
 {
     launch_dw_table(a.logit_lens, a.B, a.T, a.U1, XW2_GRAN, a.dw_tab, st);
+    if (a.dw_prog) launch_fill32(a.dw_prog, 0u, (size_t)a.n_split * 64, st);
     const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
     static bool attr_set[16] = {false};  // > 64 KiB of dynamic LDS: opt-in once per device (read-mostly fact)
     int dev = -1;
