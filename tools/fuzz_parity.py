@@ -1,7 +1,7 @@
 """Randomised parity sweep on the GPU: random (B,T,U,H,V) and arbitrary ragged lengths (1-step
 utterances, empty targets) through the fused path against the fp64 oracle (fp32 route) / the
 rounding-point oracle (bf16 route), with the tolerances of tests/helpers.py.
-   python tools/fuzz_parity.py [n_fp32] [n_bf16] [seed] [max_H/4] [max_V/4] [n_bf16x3]
+   python tools/fuzz_parity.py [n_fp32] [n_bf16] [seed] [max_H/4] [max_V/4] [n_bf16x3] [n_f16x2]
 (the bf16x3 route runs the fp32 cases' shape distribution — any H, V, padded by the operator — at the fp32 tolerances)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,10 +39,12 @@ if __name__ == "__main__":
     maxh = int(sys.argv[4]) if len(sys.argv) > 4 else 160
     maxv = int(sys.argv[5]) if len(sys.argv) > 5 else 79
     nx3 = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    nx2 = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     bad = 0
-    for it in range(n32 + n16 + nx3):
+    for it in range(n32 + n16 + nx3 + nx2):
         bf = n32 <= it < n32 + n16
-        x3 = it >= n32 + n16
+        x3 = n32 + n16 <= it < n32 + n16 + nx3
+        x2 = it >= n32 + n16 + nx3
         B = int(rng.integers(1, 6)); T = int(rng.integers(1, 70)); U = int(rng.integers(0, 40))
         if bf:
             H = int(rng.choice([128, 256, 384, 512, 640, 768, 1024, 1152, 1536])); V = 128 * int(rng.integers(1, max(2, maxv // 32) + 1))
@@ -54,9 +56,9 @@ if __name__ == "__main__":
         ll = rng.integers(1, T + 1, B); tl = rng.integers(0, U + 1, B)
         ll[rng.integers(B)] = T; tl[rng.integers(B)] = U
         d["logit_lens"] = ll.astype(np.int32); d["target_lens"] = tl.astype(np.int32)
-        tag = f"{'bf16' if bf else 'bf16x3' if x3 else 'fp32'} B={B} T={T} U={U} H={H} V={V} ll={ll.tolist()} tl={tl.tolist()}"
+        tag = f"{'bf16' if bf else 'bf16x3' if x3 else 'f16x2' if x2 else 'fp32'} B={B} T={T} U={U} H={H} V={V} ll={ll.tolist()} tl={tl.tolist()}"
         try:
-            r = run(d, "bf16" if bf else "bf16x3" if x3 else "fp32")
+            r = run(d, "bf16" if bf else "bf16x3" if x3 else "f16x2" if x2 else "fp32")
             ref = oracle_fused_bf16(d) if bf else oracle_fused(d)
             if bf:
                 assert_close_loss("costs", r["costs"], ref["costs"], rtol=BF16_LOSS_RTOL)

@@ -47,7 +47,10 @@ if SLICE:  # includes the case of commit 1f6212f (bf16, V = 128: a bias read pas
              ("fp32", (2, 9, 4, 516, 96)), ("fp32", (2, 30, 9, 1024, 260)), ("bf16", (2, 9, 4, 128, 128)),
              ("bf16", (1, 43, 27, 256, 128)), ("bf16", (2, 13, 20, 1024, 256)), ("bf16", (3, 21, 9, 640, 128))]
     CASES += [("bf16x3", (2, 9, 4, 128, 128)), ("bf16x3", (2, 13, 20, 1024, 256)), ("bf16x3", (3, 21, 9, 640, 128))]
+    CASES += [("f16x2", (2, 9, 4, 128, 128)), ("f16x2", (2, 13, 20, 1024, 256)), ("f16x2", (3, 21, 9, 640, 128))]
 else:
+    CASES += [("f16x2", s) for s in [(1, 1, 0, 128, 128), (2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024),
+                                     (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128), (1, 43, 27, 256, 128), (2, 50, 101, 512, 1024)]]
     CASES += [("bf16x3", s) for s in [(1, 1, 0, 128, 128), (2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024),
                                       (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128), (1, 43, 27, 256, 128), (2, 50, 101, 512, 1024)]]
 for dtype, (B, T, U, H, V) in CASES:
