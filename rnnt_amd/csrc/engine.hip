@@ -244,7 +244,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     const int xflags = g_flags | (variant & (RNNT_VARIANT_SEPARATE_G | RNNT_VARIANT_SEPARATE_HIDDEN |
                                              RNNT_VARIANT_FWD_LDS_RING | RNNT_VARIANT_FWD_ONE_WG_PER_TILE |
                                              RNNT_VARIANT_X3_FP32_FWD | RNNT_VARIANT_X3_FP32_DH |
-                                             RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z | RNNT_VARIANT_X2_DW_8W));
+                                             RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z | RNNT_VARIANT_X2_DW_8W | RNNT_VARIANT_X2_FWD_2WG));
     rnnt_engine_ws_layout L;
     layout(B, T, U1, H, V, dtype, &L);
     if (ws_bytes < L.total)
@@ -340,7 +340,8 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
                 if (x2) launch_x2_make_hidden(h, st);
                 else launch_x3_make_hidden(h, st);  // the planes the backward reads
             } else if (x2) {
-                launch_joint_fwd_x2(h, st);
+                if ((xflags & RNNT_VARIANT_X2_FWD_2WG) && x2_fwd_d_ok(U1, H, V)) launch_joint_fwd_x2d(h, st);
+                else launch_joint_fwd_x2(h, st);
             } else if ((xflags & (RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z)) && x3_fwd_d_ok(U1, H, V)) {
                 launch_joint_fwd_x3d(h, (xflags & RNNT_VARIANT_X3_FWD_8W) ? 8 : 4, st);
             } else {

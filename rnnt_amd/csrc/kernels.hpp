@@ -179,7 +179,9 @@ void launch_x2_make_hidden(const X3Args &a, hipStream_t st);
 void launch_x2_split_g(const X3Args &a, hipStream_t st);
 void launch_x2_zero_padding(const X3Args &a, int what, hipStream_t st);
 void launch_x2_pack_w(const X3Args &a, float *scales, hipStream_t st);  // s_W from max |W|, then both packs
-void launch_joint_fwd_x2(const X3Args &a, hipStream_t st);
+void launch_joint_fwd_x2(const X3Args &a, hipStream_t st);   // one 512-register wave per SIMD
+bool x2_fwd_d_ok(int U1, int H, int V);
+void launch_joint_fwd_x2d(const X3Args &a, hipStream_t st);  // two 4-wave workgroups per CU, A in registers (RNNT_VARIANT_X2_FWD_2WG)
 void launch_dhidden_x2(const X3Args &a, hipStream_t st);
 void launch_dw_x2(const X3Args &a, hipStream_t st);  // v_mfma_f32_16x16x32_bf16, two products per MFMA (RNNT_VARIANT_X3_DW_P16)
 

@@ -1384,6 +1384,314 @@ void launch_joint_fwd_x2(const X3Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_joint_fwd_x2, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
 }
 
+// ---------------------------------------------------------------------------------------
+// k_joint_fwd_x2d: the forward as TWO 4-wave workgroups per CU that share no barrier (k_joint_fwd_x3d's form on two planes).
+// What k_joint_fwd_x2 cannot overlap — a pass end is bound by the CU's store rate (256 KiB of logits per pass at ~13 B/clk: ~19 k of
+// a tile's 233 k cycles, twice), every LDS-DMA issue blocks its wave ~80 cycles, the barrier, the first fragment reads — the SIMD's
+// other wave, from the other workgroup, fills with MFMAs.
+//  * workgroup = 4 waves, tile = 128 consecutive cells, pass = 256 logits columns; wave w owns rows 32w .. 32w+31 of the tile for ALL
+//    256 columns of the pass: one M tile x 8 N tiles = 128 accumulator registers, 256 registers per wave -> two waves per SIMD;
+//  * A never touches LDS: lane (i, half) of wave w produces 2^14 tanh(enc + pred) of ITS fragment slot (row 32w + i, k = 16c + 8 half ..)
+//    one k-step ahead, splits it and keeps the two planes in 8 registers (first pass: also stored for k_dw_x2);
+//  * W k-steps (2 planes x 8 tiles = 16 KiB: the forward pack, half a 512-column pass at a time) by LDS-DMA into a 3-slot ring, 4 pieces
+//    per wave, requested TWO k-steps ahead; one barrier per k-step publishes a slot;
+//  * per tile q: 2 fragment reads (hi, mid of W tile q, issued during tile q-1's MFMAs) feed 3 MFMAs on one accumulator tile;
+//  * DMA issues, operand loads, the 16 production pieces and the hidden stores ride between the 24 MFMAs of a k-step, in one fixed
+//    order per k-step (D x4, L x4, S x2) so that every vmcnt is a count;
+//  * pass end, statistics, finalisation: as k_joint_fwd_x2 (a row's 256 columns of a pass sit in ONE wave).
+// Persistent workgroups, 2 per CU (50 KiB of LDS each), tiles from one atomic counter.  H % 32 == 0 (k loop unrolled by 2), V % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define XD2_WSLOT 16384
+#define XD2_NSLOT 3
+__global__ __launch_bounds__(256, 2) void k_joint_fwd_x2d(X3Args a, const int ntiles)
+{
+    constexpr int ROWS = 128, ND = 4;  // tile rows; W DMA pieces per wave and k-step
+    // [0, 48 KiB): W ring;  then: s_den[128], s_part[128][2], s_next[2]
+    extern __shared__ __attribute__((aligned(1024))) char s_fd[];
+    float *s_den = (float *)(s_fd + XD2_NSLOT * XD2_WSLOT);
+    float *s_part = s_den + ROWS;  // [row][max, sum]
+    int *s_next = (int *)(s_part + 2 * ROWS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int H = a.H, V = a.V, KC = H / 16, U1 = a.U1, T = a.T;
+    const int npass = (V + 255) / 256;
+    const long cells = (long)a.B * T * U1;
+    const float unscale = X2_INV_SH * a.scales[1];
+
+    const int lds0 = (int)(size_t)(lds_vptr)s_fd;
+    const int wb = lds0 + 16 * lane;  // W read: tile q of plane p of ring slot s at wb + s * XD2_WSLOT + p * 8192 + q * 1024
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(a.wpack_fwd, 0, ((V + 511) / 512) * KC * 32768, 0x00020000);
+    const int wvo = lane * 16;
+
+    if (tid == 0) s_next[0] = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    int tile = s_next[0];
+    for (int it = 1; tile < ntiles; ++it) {
+        if (tid == 0) s_next[it & 1] = (int)atomicAdd(a.counter, 1u);
+        const long row0 = (long)tile * ROWS;
+        if (tid < ROWS) { s_part[2 * tid] = RNNT_NEG_INF; s_part[2 * tid + 1] = 0.f; }
+        __syncthreads();  // s_next, s_part visible; every wave is past the previous tile's LDS reads
+        const int next = s_next[it & 1];
+        bool dead;  // a tile entirely in the time steps past one utterance's length: hidden rows only (k_joint_fwd_x2)
+        {
+            const long per = (long)T * U1, c_last = row0 + ROWS - 1;
+            const long b_first = row0 / per;
+            dead = c_last < cells && c_last / per == b_first && (row0 - b_first * per) / U1 >= len_t(a.logit_lens, (int)b_first, T);
+        }
+        const long prow = row0 + 32 * wave + i;
+        const long pc_ = prow < cells ? prow : cells - 1;  // rows past the lattice (last tile): the last cell again, same bits to the same place
+        const int pu = (int)(pc_ % U1);
+        const long pbt = pc_ / U1;
+        const int pt = (int)(pbt % T), pb = (int)(pbt / T);
+        const float *ep = a.enc + (long)pb * a.enc_sb + (long)pt * a.enc_st + 8 * half;
+        const float *pp = a.pred + ((long)pb * U1 + pu) * H + 8 * half;
+        u32x4 *hdst = (u32x4 *)a.hidden + pc_ * (H / 8) + half;  // + 2c: this lane's 16 bytes of k-step c; planes `ps` apart
+        const long ps = a.plane_stride / 8;
+        struct Opd { f32x4 e0, e1, p0, p1; };
+        struct Prod { f2 w[4]; float ra, rb; u32x4 ph, pm; };
+        auto op_load1 = [&](Opd &o, int kcs, int k) {  // one of the four operand loads of k index kcs
+            if (k == 0) o.e0 = *(const f32x4 *)(ep + 16 * kcs);
+            else if (k == 1) o.e1 = *(const f32x4 *)(ep + 16 * kcs + 4);
+            else if (k == 2) o.p0 = *(const f32x4 *)(pp + 16 * kcs);
+            else o.p1 = *(const f32x4 *)(pp + 16 * kcs + 4);
+        };
+        // pieces 0-7: 2^14 tanh of the 4 pairs (exp2 half, reciprocal half); 8-15: the 2-way split of each pair (hi + residuals, then mid)
+        auto prod_piece = [&](Prod &P, const Opd &o, int k) {
+            if (k < 8) {
+                const int j = k >> 1;
+                if (!(k & 1)) {
+                    const f32x4 &e = j < 2 ? o.e0 : o.e1, &pv = j < 2 ? o.p0 : o.p1;
+                    const int q = 2 * (j & 1);
+                    const f2 x = {e[q] + pv[q], e[q + 1] + pv[q + 1]};
+                    const f2 av = x * (2.0f * RNNT_LOG2E);
+                    P.w[j] = f2{__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+                } else {
+                    const f2 ex = P.w[j] + 1.0f;
+                    const f2 rr = {__builtin_amdgcn_rcpf(ex[0]), __builtin_amdgcn_rcpf(ex[1])};
+                    P.w[j] = X2_SH - (2.0f * X2_SH) * rr;
+                }
+            } else {
+                const int j = (k - 8) >> 1;
+                if (!(k & 1)) {
+                    const unsigned hh = x2_pack(P.w[j][0], P.w[j][1]);
+                    P.ph[j] = hh;
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(P.ra) : "v"(hh), "v"(P.w[j][0]));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(P.rb) : "v"(hh), "v"(P.w[j][1]));
+                } else {
+                    P.pm[j] = x2_pack(P.ra, P.rb);
+                }
+            }
+        };
+        // piece n (0..3) of this wave's share of the W k-step at pack offset `base` -> ring slot `slot`
+        auto wdma = [&](int base, int slot, int n) {
+            const int pc = wave * ND + n;  // 0..15: plane pc >> 3, tile pc & 7
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fd + slot * XD2_WSLOT + pc * 1024), 16, wvo,
+                                                     base + (pc >> 3) * 16384 + (pc & 7) * 1024, 0, 0);
+        };
+        // pack offset of k-step (pass p, k index kc): [p >> 1][kc][plane][tile 8 (p & 1) + q]
+        auto wbase = [&](int p, int kc) { return ((p >> 1) * KC + kc) * 32768 + (p & 1) * 8192; };
+
+        if (dead) {
+            for (int kc = 0; kc < KC; ++kc) {
+                Opd o; Prod P;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) op_load1(o, kc, k);
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, pc);
+                hdst[2 * kc] = P.ph; hdst[2 * kc + ps] = P.pm;
+            }
+            tile = next;
+            continue;
+        }
+
+        f32x16 acc[8];
+        u32x4 Ah, Am;   // the MFMA A fragment of the current k-step: this lane's slot of the two planes
+        Opd oset[2];    // operands of k-step cs+1 live in oset[(cs+1) & 1] during k-step cs (KC even: k loop unrolled by 2)
+        // pipeline prologue: W of k-steps 0 and 1 by DMA; A of k-step 0 produced (and stored); operands of k-step 1
+        {
+#pragma unroll
+            for (int n = 0; n < ND; ++n) wdma(wbase(0, 0), 0, n);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) wdma(KC > 1 ? wbase(0, 1) : wbase(0, 0), 1, n);
+            Opd o; Prod P;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) op_load1(oset[1], KC > 1 ? 1 : 0, k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) op_load1(o, 0, k);
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, pc);
+            hdst[0] = P.ph; hdst[ps] = P.pm;
+            Ah = P.ph; Am = P.pm;
+        }
+        int cs = 0, slot = 0;
+        int pd = KC > 2 ? 0 : 1, kd = KC > 2 ? 2 : 0;  // (pass, k index) of k-step cs + 2, the one the DMAs of k-step cs fetch
+        if (pd >= npass) { pd = npass - 1; kd = KC - 1; }
+
+        auto run_pass = [&](auto store_c, const int pass) {
+          constexpr bool STORE = decltype(store_c)::value != 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+          for (int kc0 = 0; kc0 < KC; kc0 += 2)
+#pragma unroll
+          for (int par = 0; par < 2; ++par, ++cs) {
+            const int kc = kc0 + par;
+            // W of k-step cs (this wave's share) landed: its DMAs were issued during k-step cs-2.  vmcnt retires in order;
+            // younger than them: L x4 + S x2 of k-step cs-2 and D x4 + L x4 + S x2 of k-step cs-1 (S: first pass only).
+            // First k-step of a pass: also behind the previous pass's logits stores (and the tile prologue): drain — the CU's
+            // other workgroup runs meanwhile.
+            if (kc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STORE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            x2_lds_barrier();  // publishes W slot of k-step cs; every wave is past its reads of k-step cs-1 (the slot the DMAs below refill)
+            const int ws = wb + slot * XD2_WSLOT;
+            const int dslot = slot == 0 ? 2 : slot - 1;  // (cs + 2) % 3
+            const int dbase = wbase(pd, kd);
+            const int kcn = kc + 1 < KC ? kc + 1 : 0, kcnn = kcn + 1 < KC ? kcn + 1 : 0;
+            const Opd &ocur = oset[(par + 1) & 1];  // operands of A's k-step cs+1 (requested during the previous k-step)
+            Opd &onext = oset[par & 1];             // refilled with those of k-step cs+2
+            Prod P;
+            u32x4 b0[2], b1[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b0[p]) : "v"(ws), "n"(p * 8192));
+            // the fillers between the 24 MFMAs of the k-step, by slot index s = 3 q + m
+            auto filler = [&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                if (s < 4) wdma(dbase, dslot, s);                                       // D x4: k-step cs+2
+                else if (s < 8) op_load1(onext, kcnn, s - 4);                           // L x4: operands of A's k-step cs+2
+                else if (s < 16) prod_piece(P, ocur, s - 8);                            // A of k-step cs+1: tanh pieces
+                else if (s < 20) { prod_piece(P, ocur, 8 + 2 * (s - 16)); prod_piece(P, ocur, 9 + 2 * (s - 16)); }  // split pieces, a pair each
+                else if (s == 20 && STORE) hdst[2 * kcn] = P.ph;                         // S x2
+                else if (s == 21 && STORE) hdst[2 * kcn + ps] = P.pm;
+            };
+            auto tile_q = [&](auto q_c, const u32x4 (&bc)[2], u32x4 (&bn)[2]) {
+                constexpr int q = decltype(q_c)::value;
+                if (q < 7) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[p]) : "v"(ws), "n"(p * 8192 + (q < 7 ? q + 1 : 0) * 1024));
+                }
+                acc[q] = x2_mfma(Ah, bc[0], acc[q]);
+                filler(X2Int<3 * q + 0>{}); __builtin_amdgcn_sched_barrier(0);
+                acc[q] = x2_mfma(Am, bc[0], acc[q]);
+                filler(X2Int<3 * q + 1>{}); __builtin_amdgcn_sched_barrier(0);
+                acc[q] = x2_mfma(Ah, bc[1], acc[q]);
+                filler(X2Int<3 * q + 2>{}); __builtin_amdgcn_sched_barrier(0);
+                if (q < 7) {  // tile q+1's fragments (issued three MFMAs ago)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0[0]), "+v"(b0[1]) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            tile_q(X2Int<0>{}, b0, b1); tile_q(X2Int<1>{}, b1, b0); tile_q(X2Int<2>{}, b0, b1); tile_q(X2Int<3>{}, b1, b0);
+            tile_q(X2Int<4>{}, b0, b1); tile_q(X2Int<5>{}, b1, b0); tile_q(X2Int<6>{}, b0, b1); tile_q(X2Int<7>{}, b1, b0);
+            Ah = P.ph; Am = P.pm;  // (the pass's last k-step produced — and re-stored — k-step 0 of the tile's rows)
+            slot = slot == 2 ? 0 : slot + 1;
+            if (++kd == KC) { kd = 0; ++pd; }
+            if (pd >= npass) { pd = npass - 1; kd = KC - 1; }  // past the tile's last k-step: a valid k-step again, into a slot nobody reads
+          }
+          // pass complete: unscale, add the bias, store the logits, update the statistics (k_joint_fwd_x2's pass end for one M tile)
+          {
+            const int cw = 256 * pass;
+            const unsigned lane_off = (unsigned)(((4 * half) * V + 4 * i) * 4);
+            char *tile_base = (char *)(a.logits + row0 * V + cw);
+            const f32x4 b0v = cw + 4 * i < V ? *(const f32x4 *)(a.bias + cw + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 b1v = cw + 128 + 4 * i < V ? *(const f32x4 *)(a.bias + cw + 128 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            auto epilogue = [&](auto both_c) {
+                constexpr bool BOTH = decltype(both_c)::value != 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { o0[q] = fmaf(acc[q][r], unscale, b0v[q]); o1[q] = fmaf(acc[4 + q][r], unscale, b1v[q]); }
+                    char *rowp = tile_base + (long)(32 * wave + (r & 3) + 8 * (r >> 2)) * V * 4;  // wave-uniform
+                    __builtin_nontemporal_store(o0, (f32x4 *)(rowp + lane_off));
+                    if (BOTH) __builtin_nontemporal_store(o1, (f32x4 *)(rowp + lane_off + 512));
+                    float m8 = fmaxf(fmaxf(o0[0], o0[1]), fmaxf(o0[2], o0[3]));
+                    if (BOTH) m8 = fmaxf(m8, fmaxf(fmaxf(o1[0], o1[1]), fmaxf(o1[2], o1[3])));
+                    const float M = half_max_dpp(m8, half);
+                    const float nm2 = -M * RNNT_LOG2E;
+                    float e = (__builtin_amdgcn_exp2f(fmaf(o0[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[1], RNNT_LOG2E, nm2))) +
+                              (__builtin_amdgcn_exp2f(fmaf(o0[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o0[3], RNNT_LOG2E, nm2)));
+                    if (BOTH)
+                        e += (__builtin_amdgcn_exp2f(fmaf(o1[0], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[1], RNNT_LOG2E, nm2))) +
+                             (__builtin_amdgcn_exp2f(fmaf(o1[2], RNNT_LOG2E, nm2)) + __builtin_amdgcn_exp2f(fmaf(o1[3], RNNT_LOG2E, nm2)));
+                    const float S_ = half_sum_dpp(e, half);  // lanes 31 / 63 hold the sums
+                    if (i == 31) {
+                        float *sp = s_part + (32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
+                        const float m_o = sp[0], s_o = sp[1];
+                        const float mn = fmaxf(m_o, M);
+                        sp[0] = mn;
+                        sp[1] = s_o * __builtin_amdgcn_exp2f((m_o - mn) * RNNT_LOG2E) + S_ * __builtin_amdgcn_exp2f((M - mn) * RNNT_LOG2E);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one row slot at a time
+                }
+            };
+            if (cw + 128 < V) epilogue(X2Int<1>{});
+            else epilogue(X2Int<0>{});
+          }
+        };
+        run_pass(X2Int<1>{}, 0);
+        for (int pass = 1; pass < npass; ++pass) run_pass(X2Int<0>{}, pass);
+
+        // ---- log-softmax denominators and the two log-probs of every lattice cell (as k_joint_fwd_x2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every logits / hidden store of the workgroup has left its wave; s_part complete; the over-issued DMAs landed
+        if (tid < ROWS) s_den[tid] = s_part[tid * 2] + __logf(s_part[tid * 2 + 1]);
+        __syncthreads();
+        {
+            const int row = tid & (ROWS - 1), which = tid / ROWS;
+            const long cell = row0 + row;
+            if (cell < cells) {
+                const int u = (int)(cell % U1);
+                const long bt = cell / U1;
+                const int t = (int)(bt % T), b = (int)(bt / T);
+                const int Ub = len_u(a.target_lens, b, U1);
+                if (t < len_t(a.logit_lens, b, T) && u <= Ub) {
+                    const float den = s_den[row];
+                    const float *lrow = a.logits + cell * V;
+                    const long si = skew_index(b, t, u, a.D, U1);
+                    if (which == 0) {
+                        const float lb = __hip_atomic_load(lrow + a.blank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.denom_s[si] = den;
+                        a.lpb_s[si] = lb - den;
+                    } else {
+                        float le = 0.f;
+                        if (u < Ub) {
+                            const int y = a.targets[(long)b * (U1 - 1) + u];
+                            le = __hip_atomic_load(lrow + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - den;
+                        }
+                        a.lpe_s[si] = le;
+                    }
+                }
+            }
+        }
+        tile = next;
+    }
+}
+
+bool x2_fwd_d_ok(int U1, int H, int V) { return x2_fwd_ok(U1, H, V) && H % 32 == 0; }
+
+void launch_joint_fwd_x2d(const X3Args &a, hipStream_t st)
+{
+    static bool attr_set[16] = {false};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    const int lds = XD2_NSLOT * XD2_WSLOT + 128 * 4 + 128 * 2 * 4 + 16;
+    if (dev < 0 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_joint_fwd_x2d, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0) attr_set[dev] = true;
+    }
+    const long cells = (long)a.B * a.T * a.U1;
+    const int ntiles = (int)((cells + 127) / 128);
+    launch_fill32(a.counter, 0u, 4, st);  // tile counter of the persistent workgroups
+    const int nwg = ntiles < 2 * a.n_cu ? ntiles : 2 * a.n_cu;  // two workgroups per CU
+    hipLaunchKernelGGL(k_joint_fwd_x2d, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+}
+
 void launch_x2_pack_w(const X3Args &a, float *scales, hipStream_t st)
 {
     hipLaunchKernelGGL(k_x2_wscale, dim3(1), dim3(1024), 0, st, a.W, (long)a.V * a.H / 4, scales);
