@@ -592,7 +592,7 @@ def test_inputs_ending_at_unmapped_pages():
                          capture_output=True, text=True, timeout=600, cwd=root)
     tail = (out.stdout[-1500:] + "\n" + out.stderr[-1500:])
     assert out.returncode == 0, "guard sweep died (memory fault = an input over-read):\n" + tail
-    assert "guard sweep clean: 12 cases" in out.stdout and "guard sweep of the other entry points clean" in out.stdout, tail
+    assert "guard sweep clean: 15 cases" in out.stdout and "guard sweep of the other entry points clean" in out.stdout, tail
 
 
 # ---------------------------------------------------------------- full-size properties
