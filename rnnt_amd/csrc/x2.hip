@@ -1005,7 +1005,7 @@ size_t x2_wpack_fwd_bytes(int H, int V) { return (size_t)((V + 511) / 512) * (H 
 // and a k-step of 48 MFMAs no longer covers it).
 // The accumulators hold 2^14 s_W (logits - bias): the pass end multiplies by 2^-14 / s_W and adds the bias (one fma; the bias
 // cannot ride in the accumulators' initial value here: the padding columns' -1e30 would overflow under the scale).
-// Persistent workgroups, one per CU (83 KiB of LDS), tiles from one atomic counter.  Requires H % 128 == 0, V % 128 == 0.
+// Persistent workgroups, one per CU (115 KiB of LDS), tiles from one atomic counter.  Requires H % 128 == 0, V % 128 == 0.
 // ---------------------------------------------------------------------------------------
 #define XF2_WSLOT 32768
 #define XF2_ASLOT 8192
