@@ -22,7 +22,7 @@ for name, var in (("f16x2", 0), ("f16x2 fwd=2wg", engine.VARIANT_X2_FWD_2WG), ("
         first = first or r
         rel = [abs(a - b) / abs(b) for a, b in zip(r, ref)]
         # (checksums are sums of |entries|: the bias gradient's carries the cancellation noise of 6.4 M cells, 1e-5 on every route)
-        flag = "" if r == first and rel[0] < 1e-6 and max(rel) < 1e-4 else "   <-- DIFFERS"
+        flag = "" if r == first and rel[0] < 1e-6 and max(rel[:4]) < 1e-4 and rel[4] < 1e-3 else "   <-- DIFFERS"
         bad += bool(flag)
         print(f"{name:18s}", ["%.9g" % v for v in r], "rel", ["%.1e" % v for v in rel], flag, flush=True)
 print("bad runs:", bad)
