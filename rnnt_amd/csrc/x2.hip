@@ -43,6 +43,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define X2_CLOCK_STAMP(SLOT) do {} while (0)
 #endif
 
+// compile-time experiment switches (-DX2_NT=bits): 1 non-temporal logits loads in k_dhidden_x2, 2 non-temporal operand DMAs in k_dw_x2<4>
+#ifndef X2_NT
+#define X2_NT 0
+#endif
 #define X2_SH 16384.0f          // scale of the hidden operand (|tanh| <= 1)
 #define X2_INV_SH (1.0f / 16384.0f)
 #define X2_F16_MAX 65504.0f
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
                 } else {
                     constexpr int p = (n >> 2) & 1;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + otile * XW2_TILE + DST * XW2_STAGE + p * XW2_PLANE + 1024 * i),
-                                                             16, soff[i], 0, 0, 0);
+                                                             16, soff[i], 0, 0, (X2_NT & 2) ? 2 : 0);  // (experiment 2: aux = 2, non-temporal)
                 }
             };
             // 8 transposed reads of plane P of the A / B operand (inline asm: hipcc guards every LDS read it can see behind
@@ -689,8 +693,13 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
         const int cc = c < VC ? c : VC - 1;
         if (FIRST) {
             const f32x4 *p = (const f32x4 *)xsrc + 4 * cc + 2 * half;
-            if (part & 1) r.x0 = p[0];
-            if (part & 2) r.x1 = p[1];
+            if (X2_NT & 1) {  // experiment: the logits are read once, by this CU only -> non-temporal loads
+                if (part & 1) r.x0 = __builtin_nontemporal_load(p);
+                if (part & 2) r.x1 = __builtin_nontemporal_load(p + 1);
+            } else {
+                if (part & 1) r.x0 = p[0];
+                if (part & 2) r.x1 = p[1];
+            }
         } else {
             const u32x4 *p = (const u32x4 *)xsrc + 8 * (cc >> 1) + 2 * (cc & 1) + half;
             if (part & 1) r.x0 = __builtin_bit_cast(f32x4, p[0]);
