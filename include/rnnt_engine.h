@@ -98,6 +98,7 @@ void rnnt_engine_set_debug(void *buf);
 #define RNNT_VARIANT_X3_FWD_2WG 16384       /* two 4-wave workgroups per CU, 128-cell tiles */
 #define RNNT_VARIANT_X3_FWD_8W 65536        /* one 8-wave workgroup per CU, 256-cell tiles */
 #define RNNT_VARIANT_X2_FWD_2WG 1048576      /* RNNT_DTYPE_F32_F16X2 only: the forward as two 4-wave workgroups per CU (k_joint_fwd_x2d: A in registers, 256-column passes) */
+#define RNNT_VARIANT_X2_DW_P16 2097152       /* RNNT_DTYPE_F32_F16X2 only: dW on v_mfma_f32_16x16x32_f16 (k_dw_x2p: a k = 32 MFMA spans two 16-cell ring stages) */
 #define RNNT_VARIANT_X2_DW_8W 524288        /* RNNT_DTYPE_F32_F16X2 only: dW as 8 waves per workgroup (two per SIMD, k_dw_x2<8>) instead of the default 4: measured equal (15.5 ms), kept for the record */
 #define RNNT_VARIANT_X3_FWD_Z 262144        /* k_joint_fwd_x3z: one wave per SIMD with two M tiles (256 x 256 tiles, A in registers) */
 /* RNNT_DTYPE_F32_BF16X3 only: dW on v_mfma_f32_16x16x32_bf16 with two of the six products per MFMA (k_dw_x3p, round 4)

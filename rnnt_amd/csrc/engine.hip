@@ -244,7 +244,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
     const int xflags = g_flags | (variant & (RNNT_VARIANT_SEPARATE_G | RNNT_VARIANT_SEPARATE_HIDDEN |
                                              RNNT_VARIANT_FWD_LDS_RING | RNNT_VARIANT_FWD_ONE_WG_PER_TILE |
                                              RNNT_VARIANT_X3_FP32_FWD | RNNT_VARIANT_X3_FP32_DH |
-                                             RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z | RNNT_VARIANT_X2_DW_8W | RNNT_VARIANT_X2_FWD_2WG));
+                                             RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z | RNNT_VARIANT_X2_DW_8W | RNNT_VARIANT_X2_FWD_2WG | RNNT_VARIANT_X2_DW_P16));
     rnnt_engine_ws_layout L;
     layout(B, T, U1, H, V, dtype, &L);
     if (ws_bytes < L.total)

@@ -526,6 +526,280 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_dw_x2p: k_dw_x2 on v_mfma_f32_16x16x32_f16 — the shape on which the chip holds a higher clock under a dense 16-bit matrix
+// stream (MI355X_MICROARCH.md 'DVFS give-back' item 7; tools/mfma_shape.hip) — for the kernel that holds the lowest one (1.75 GHz).
+// Same tile (256 v x 256 h, wave 128 x 128 = 8 x 8 tiles of 16 x 16: 256 accumulator registers), same ring of four 16-cell stages,
+// same DMAs; a k = 32 MFMA spans TWO stages (a "pair": lane groups 0, 1 read cells 0-15 from ring stage ST, groups 2, 3 cells 16-31
+// from stage ST + 1: a constant 8 KiB in their base registers — pairs start at even stages, so ST + 1 never wraps).  One barrier
+// per pair; the 16 DMA pieces of the next pair ride in the first product; products ah.bh, am.bh, ah.bm = 3 x 64 MFMAs of 16 cycles.
+// Fragment of a 16-column tile: lane (g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3) reads rows 8 (g & 1) + 4 sec + q (sec = 0, 1)
+// at chunk 2 mt + (p >> 1), + 8 (p & 1) bytes: two ds_read_b64_tr_b16 = the lane's 8 cells of column 16 mt + (lane & 15).
+// The MFMAs are inline asm on "+a" accumulators (left to hipcc the 64 four-register tiles wander between the register files).
+// RNNT_VARIANT_X2_DW_P16.
+// ---------------------------------------------------------------------------------------
+struct X2PFrag { u32x2 lo[8], hi[8]; };  // 8 tiles of 16 columns: cells 0-3 / 4-7 of the lane's 8
+#define X2P_LANDED(f, N)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                         \
+                 : "+v"(f.lo[0]), "+v"(f.lo[1]), "+v"(f.lo[2]), "+v"(f.lo[3]), "+v"(f.lo[4]), "+v"(f.lo[5]), "+v"(f.lo[6]),  \
+                   "+v"(f.lo[7]), "+v"(f.hi[0]), "+v"(f.hi[1]), "+v"(f.hi[2]), "+v"(f.hi[3]), "+v"(f.hi[4]), "+v"(f.hi[5]),  \
+                   "+v"(f.hi[6]), "+v"(f.hi[7])                                                                      \
+                 :: "memory")
+typedef __attribute__((ext_vector_type(4))) float f32x4_p;
+
+__global__ __launch_bounds__(256, 1) void k_dw_x2p(X3Args a)
+{
+    static_assert(XW2_NST == 4, "pairs of stages");
+    extern __shared__ __attribute__((aligned(1024))) char s_ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.H, V = a.V;
+    const int n_vblk = (V + 255) / 256, n_hblk = (H + 255) / 256;
+    const int tiles = n_vblk * n_hblk;
+    const int total = tiles * a.n_split;
+    int id = blockIdx.x;  // XCD-aware remap: the tiles of one split share an XCD's L2
+    {
+        const int q8 = total / 8, r8 = total % 8, x = id % 8;
+        id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + id / 8;
+    }
+    const int tile = id % tiles, split = id / tiles;
+    const int vb = tile / n_hblk, hb = tile % n_hblk;
+    const long *tab = a.dw_tab;
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+
+    f32x4_p acc[8][8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            acc[mt][nt] = f32x4_p{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(acc[mt][nt]));  // (an accumulator-file value from here on)
+        }
+    // db: the wave's M tile(s) of 32 v (k_dw_x2's assignment) = two 16-row tiles each -> selector columns 0, 1 (2, 3)
+    const bool do_b = hb < 2;  // workgroup-uniform
+    const int bsel0 = n_hblk >= 2 ? (hb & 1) * 2 + wn : wn;
+    const int ntl = n_hblk < 2 ? 4 : 2;
+    f32x4_p dacc = {0.f, 0.f, 0.f, 0.f};
+    const int g4 = lane >> 4;
+
+    if (g_hi > g_lo) {
+        // ---- DMA source of this wave's operand tile (as k_dw_x2)
+        const bool is_g = wave < 2;
+        int col0 = (is_g ? vb : hb) * 256 + 128 * (wave & 1);
+        if (col0 >= (is_g ? V : H)) col0 = 0;
+        const char *pbase[2];
+        long rstride;
+        if (is_g) {
+            pbase[0] = (const char *)a.logits + 4L * col0;
+            pbase[1] = (const char *)a.logits + 4L * col0 + 64;
+            rstride = 4L * V;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) pbase[p] = (const char *)(a.hidden + p * a.plane_stride) + 2L * col0;
+            rstride = 2L * H;
+        }
+        int soff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int jg = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
+            const int cb = is_g ? 128 * (jg >> 2) + 16 * (jg & 3) : 16 * jg;
+            soff[i] = (int)((4 * i + (lane >> 4)) * rstride) + cb;
+        }
+        long row_first = 0;
+        // ---- fragment read bases: one per (tile, sec) and operand; lane groups 2, 3 read the pair's second stage
+        const int q = (lane & 15) >> 2, pp = lane & 3;
+        const int lds0 = (int)(size_t)(lds_vptr)s_ring;
+        const int upper = g4 >= 2 ? XW2_STAGE : 0;
+        auto frag_off = [&](int mt, int sec) {
+            const int row = 8 * (g4 & 1) + 4 * sec + q;
+            const int ch = 2 * mt + (pp >> 1);
+            const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+            return 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1) + upper;
+        };
+        int aB[8][2], bB[8][2];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                aB[mt][sec] = lds0 + wm * XW2_TILE + frag_off(mt, sec);
+                bB[mt][sec] = lds0 + (2 + wn) * XW2_TILE + frag_off(mt, sec);
+            }
+        int sB[4][2];  // db: the (up to four) 16-row tiles this wave sums, read once more through their own bases
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) sB[kk][sec] = lds0 + wm * XW2_TILE + frag_off((2 * (bsel0 + 2 * (kk >> 1)) + (kk & 1)) & 7, sec);
+
+        // one pair of k-steps on ring stages ST, ST + 1 (compile-time: every LDS offset is an immediate)
+        auto kpair = [&](auto st_c, long pr, f32x4_p &dacc) {
+            constexpr int ST = decltype(st_c)::value, DST = (ST + 2) % 4;
+            __amdgpu_buffer_rsrc_t rs[2][2];  // [stage of the next pair][plane]
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    rs[sg][p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (2 * (pr + 1) + sg) * XW2_ROWS) * rstride), 0,
+                                                                  (int)(XW2_ROWS * rstride), 0x00020000);
+            auto dma_piece = [&](auto n_c) {  // piece n (0..15) of the next pair: stage n >> 3, plane (n >> 2) & 1, rows 4 (n & 3) ..
+                constexpr int n = decltype(n_c)::value, sg = n >> 3, p = (n >> 2) & 1, i = n & 3;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[sg][p], (lds_vptr)(s_ring + wave * XW2_TILE + (DST + sg) * XW2_STAGE + p * XW2_PLANE + 1024 * i),
+                                                         16, soff[i], 0, 0, 0);
+            };
+            auto read2 = [&](u32x2 &lo, u32x2 &hi, int b0, int b1, auto pl_c) {
+                constexpr int off = ST * XW2_STAGE + decltype(pl_c)::value * XW2_PLANE;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(b0), "n"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(b1), "n"(off));
+            };
+            auto read_tile = [&](X2PFrag &f, const int (&base)[8][2], auto pl_c, int t) { read2(f.lo[t], f.hi[t], base[t][0], base[t][1], pl_c); };
+            auto frag = [&](const X2PFrag &f, int t) { return u32x4{f.lo[t][0], f.lo[t][1], f.hi[t][0], f.hi[t][1]}; };
+            // the pair landed (its DMAs were issued during the previous pair / the prologue); every wave is past its reads of the
+            // previous pair, whose two ring stages the DMAs below refill
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x2_lds_barrier();
+            X2PFrag Ah, Bh, Am, Bm;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { read_tile(Ah, aB, X2Int<0>{}, t); read_tile(Bh, bB, X2Int<0>{}, t); }
+            X2P_LANDED(Ah, 0);
+            X2P_LANDED(Bh, 0);
+            // one product: 64 MFMAs, a filler slot after each of its 8 tile rows
+            auto product = [&](const X2PFrag &fa, const X2PFrag &fb, auto which_c) {
+                constexpr int W = decltype(which_c)::value;
+                u32x4 bv[8];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) bv[nt] = frag(fb, nt);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const u32x4 av = frag(fa, mt);
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(av), "v"(bv[nt]));
+                    if (W == 0) {  // beside ah.bh: A's mid plane; the 16 DMA pieces of the next pair, two per tile row
+                        read_tile(Am, aB, X2Int<1>{}, mt);
+                        if (mt == 0) { dma_piece(X2Int<0>{}); dma_piece(X2Int<1>{}); }
+                        if (mt == 1) { dma_piece(X2Int<2>{}); dma_piece(X2Int<3>{}); }
+                        if (mt == 2) { dma_piece(X2Int<4>{}); dma_piece(X2Int<5>{}); }
+                        if (mt == 3) { dma_piece(X2Int<6>{}); dma_piece(X2Int<7>{}); }
+                        if (mt == 4) { dma_piece(X2Int<8>{}); dma_piece(X2Int<9>{}); }
+                        if (mt == 5) { dma_piece(X2Int<10>{}); dma_piece(X2Int<11>{}); }
+                        if (mt == 6) { dma_piece(X2Int<12>{}); dma_piece(X2Int<13>{}); }
+                        if (mt == 7) { dma_piece(X2Int<14>{}); dma_piece(X2Int<15>{}); }
+                    } else if (W == 1) {  // beside am.bh: B's mid plane
+                        read_tile(Bm, bB, X2Int<1>{}, mt);
+                    }
+                }
+            };
+            product(Ah, Bh, X2Int<0>{});
+            X2P_LANDED(Am, 0);
+            product(Am, Bh, X2Int<1>{});
+            X2P_LANDED(Bm, 0);
+            if (do_b) {  // db[v] += sum over the pair's 32 cells of hi and of mid: selector column kk for the wave's tile kk
+                u32x2 l0[4], h0[4], l1[4], h1[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (kk < ntl) {
+                        read2(l0[kk], h0[kk], sB[kk][0], sB[kk][1], X2Int<0>{});
+                        read2(l1[kk], h1[kk], sB[kk][0], sB[kk][1], X2Int<1>{});
+                    }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (kk < ntl) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0[kk]), "+v"(h0[kk]), "+v"(l1[kk]), "+v"(h1[kk]) :: "memory");
+                        const u32x4 f0 = {l0[kk][0], l0[kk][1], h0[kk][0], h0[kk][1]}, f1 = {l1[kk][0], l1[kk][1], h1[kk][0], h1[kk][1]};
+                        const unsigned sv = (lane & 15) == kk ? 0x3c003c00u : 0u;  // fp16 ones in column kk, every k
+                        const u32x4 sa = {sv, sv, sv, sv};
+                        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(dacc) : "v"(f0), "v"(sa));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(dacc) : "v"(f1), "v"(sa));
+                    }
+            }
+            product(Ah, Bm, X2Int<2>{});
+        };
+        auto dma_pair = [&](long pr) {  // pipeline prologue: this wave's 16 pieces of pair pr -> ring stages 0, 1
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int sg = n >> 3, p = (n >> 2) & 1, i = n & 3;
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(pbase[p] + (row_first + (2 * pr + sg) * XW2_ROWS) * rstride), 0, (int)(XW2_ROWS * rstride), 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(s_ring + wave * XW2_TILE + sg * XW2_STAGE + p * XW2_PLANE + 1024 * i),
+                                                         16, soff[i], 0, 0, 0);
+            }
+        };
+
+        // soft lockstep of the split's tiles (k_dw_x2's)
+        constexpr int DW_LAG = 6, DW_NAPS = 256;
+        int *prog = a.dw_prog ? a.dw_prog + split * 16 : nullptr;
+        bool sync_on = prog != nullptr && tiles > 1 && tiles <= 16;
+        const int *nb = prog ? prog + (tile + 1 < tiles ? tile + 1 : 0) : nullptr;
+        int nb_at = 0x7fffffff;
+        int done = 0;  // 16-cell k-steps behind this workgroup, over all ranges
+        auto lockstep = [&](int mine) {
+            int naps = 0;
+            while (sync_on && nb_at + DW_LAG + 4 < mine) {
+                if (++naps > DW_NAPS) { sync_on = false; break; }
+                __builtin_amdgcn_s_sleep(4);
+                asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(nb_at) : "s"(nb) : "memory");
+            }
+            if (sync_on) {
+                if (tid == 0) __hip_atomic_store(prog + tile, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(nb_at) : "s"(nb) : "memory");
+            }
+        };
+        int ub = 0;
+        while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;
+        for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
+            const long cum0 = tab[B + 1 + ub], cum1 = ub + 1 < B ? tab[B + 1 + ub + 1] : nlive;
+            const long ge = cum1 < g_hi ? cum1 : g_hi;
+            if (ge <= gq) continue;
+            const long np = ge - gq;  // 32-cell pairs of this range (one per live granule)
+            row_first = (tab[ub] + (gq - cum0)) * XW2_GRAN;
+            gq = ge;
+            dma_pair(0);
+            for (long pr = 0;;) {  // the ring stages of a pair are 2 (pr % 2), + 1: unrolled by 2
+                if (pr >= np) break;
+                lockstep(done + 2 * (int)pr);
+                kpair(X2Int<0>{}, pr, dacc); ++pr;
+                if (pr >= np) break;
+                kpair(X2Int<2>{}, pr, dacc); ++pr;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the ring
+            x2_lds_barrier();                                  // is refilled / the kernel exits
+            done += 2 * (int)np;
+        }
+        if (prog && tid == 0) __hip_atomic_store(prog + tile, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the last MFMAs' results (asm: hipcc pads nothing) before the accumulators are read below
+
+    // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r of tile (mt, nt):
+    // v = v0 + 16 mt + 4 (lane >> 4) + r, h = h0 + 16 nt + (lane & 15).
+    const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
+    float *sw = a.slab_w + (long)split * V * H;
+    const float rw = a.dw_rescale, rb = a.db_rescale;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + 16 * mt + 4 * g4 + r;
+            if (v < V) {
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const int h = h0 + 16 * nt + (lane & 15);
+                    if (h < H) sw[(long)v * H + h] = acc[mt][nt][r] * rw;
+                }
+            }
+        }
+    if (do_b && (lane & 15) < ntl) {  // column k of the selector products holds the sums of 16-row tile k of this wave's share
+        const int k = lane & 15;
+        const int mt = 2 * (bsel0 + 2 * (k >> 1)) + (k & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + 16 * mt + 4 * g4 + r;
+            if (v < V) a.slab_b[(long)split * V + v] = dacc[r] * rb;
+        }
+    }
+}
+
 void launch_dw_x2(const X3Args &a, hipStream_t st)
 {
     launch_dw_table(a.logit_lens, a.B, a.T, a.U1, XW2_GRAN, a.dw_tab, st);
@@ -537,8 +811,10 @@ void launch_dw_x2(const X3Args &a, hipStream_t st)
     if (dev < 0 || !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)k_dw_x2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
         (void)hipFuncSetAttribute((const void *)k_dw_x2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
+        (void)hipFuncSetAttribute((const void *)k_dw_x2p, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
         if (dev >= 0) attr_set[dev] = true;
     }
+    if (a.flags & RNNT_VARIANT_X2_DW_P16) { hipLaunchKernelGGL(k_dw_x2p, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a); return; }
     if (a.flags & RNNT_VARIANT_X2_DW_8W) hipLaunchKernelGGL(k_dw_x2<8>, dim3(tiles * a.n_split), dim3(512), 4 * XW2_TILE, st, a);
     else hipLaunchKernelGGL(k_dw_x2<4>, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
 }

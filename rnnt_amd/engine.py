@@ -122,6 +122,7 @@ VARIANT_X3_FWD_2WG = 16384  # bf16x3 forward as two 4-wave workgroups per CU (k_
 VARIANT_X3_FWD_8W = 65536   # ... as one 8-wave workgroup per CU (k_joint_fwd_x3d<8>)
 VARIANT_X3_FWD_Z = 262144   # bf16x3 forward as k_joint_fwd_x3z (one wave per SIMD, two M tiles per wave, 256 x 256 tiles)
 VARIANT_X2_FWD_2WG = 1048576  # f16x2 forward as two 4-wave workgroups per CU (k_joint_fwd_x2d)
+VARIANT_X2_DW_P16 = 2097152  # f16x2 dW on v_mfma_f32_16x16x32_f16 (k_dw_x2p)
 VARIANT_X2_DW_8W = 524288   # f16x2 dW as 8 waves per workgroup (two per SIMD, k_dw_x2<8>) instead of the default 4 (measured equal)
 VARIANT_X3_DW_P16 = 131072  # bf16x3 dW on v_mfma_f32_16x16x32_bf16, two products per MFMA (k_dw_x3p) instead of the default k_dw_x3
 STAGES_ALL = 255

@@ -8,7 +8,7 @@ from tests.test_gpu_parity import _dev
 import rnnt_amd
 e = rnnt_amd.engine
 VAR = {"dw_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH, "dw_dhidden": e.VARIANT_X3_FP32_FWD, "all": 0,
-       "fwd_2wg": e.VARIANT_X2_FWD_2WG, "dw8_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH | e.VARIANT_X2_DW_8W}
+       "fwd_2wg": e.VARIANT_X2_FWD_2WG, "dwp_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH | e.VARIANT_X2_DW_P16, "dw8_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH | e.VARIANT_X2_DW_8W}
 shapes = [(2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024), (2, 13, 20, 1024, 256), (3, 21, 9, 640, 128), (2, 130, 50, 512, 256), (4, 100, 24, 512, 1024)]
 for variant in sys.argv[1:] or ["dw_only"]:
     for shape in shapes:

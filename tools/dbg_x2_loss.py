@@ -15,7 +15,7 @@ def run(dt, var=0):
 ref = run("fp32")
 print("fp32 ", ["%.9g" % v for v in ref])
 bad = 0
-for name, var in (("f16x2", 0), ("f16x2 fwd=2wg", engine.VARIANT_X2_FWD_2WG), ("f16x2 fwd=fp32", engine.VARIANT_X3_FP32_FWD), ("f16x2 fwd,dh=fp32", engine.VARIANT_X3_FP32_FWD | engine.VARIANT_X3_FP32_DH)):
+for name, var in (("f16x2", 0), ("f16x2 fwd=2wg", engine.VARIANT_X2_FWD_2WG), ("f16x2 dw=p16", engine.VARIANT_X2_DW_P16), ("f16x2 fwd=fp32", engine.VARIANT_X3_FP32_FWD), ("f16x2 fwd,dh=fp32", engine.VARIANT_X3_FP32_FWD | engine.VARIANT_X3_FP32_DH)):
     first = None
     for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         r = run("f16x2", var)
@@ -35,3 +35,13 @@ for name, var in (("k_joint_fwd_x2", 0), ("k_joint_fwd_x2d (2 WG / CU)", engine.
         e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     print(f"forward stage {name:30s} {sorted(ts)[3]:7.3f} ms (min {min(ts):.3f})", flush=True)
+engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, dtype="f16x2")  # G and hidden planes in place for the dW stage
+for name, var in (("k_dw_x2<4>", 0), ("k_dw_x2p (16x16x32)", engine.VARIANT_X2_DW_P16), ("k_dw_x2<8>", engine.VARIANT_X2_DW_8W)) * 2:
+    ts = []
+    for _ in range(7):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, 1 / B, outs=outs, dtype="f16x2", stage_mask=64, variant=var)
+        e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print(f"dW stage {name:30s} {sorted(ts)[3]:7.3f} ms (min {min(ts):.3f})", flush=True)
