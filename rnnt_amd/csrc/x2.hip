@@ -47,6 +47,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef X2_NT
 #define X2_NT 0
 #endif
+// -DX2_EXP=bits (what-if builds, WRONG results): 1 the forward stages only half of W's bytes (DMA pieces 0-3 of 8)
+#ifndef X2_EXP
+#define X2_EXP 0
+#endif
 #define X2_SH 16384.0f          // scale of the hidden operand (|tanh| <= 1)
 #define X2_INV_SH (1.0f / 16384.0f)
 #define X2_F16_MAX 65504.0f
@@ -1417,6 +1421,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         auto hid_store = [&](const Prod &P, int kcs) { hdst[2 * kcs] = P.ph; hdst[2 * kcs + ps] = P.pm; };
         // piece n (0..7) of this wave's share of W k-step cs -> ring slot `slot`
         auto wdma = [&](int cs, int slot, int n) {  // raw-buffer form: scalar base and offsets, one constant per-lane offset register
+            if ((X2_EXP & 1) && n >= 4) return;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_fw + slot * XF2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
                                                      (cs * 32 + wave * 8 + n) * 1024, 0, 0);
         };
@@ -1476,6 +1481,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             // with the tile prologue (vmcnt(0): DMAs of k-steps 0 and 1, operand loads, hidden stores of k-step 0).
             X2STAMP(0);
             if (kc < 2) { if (kc == 0 && STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else if (X2_EXP & 1) { if (STORE) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
             else if (STORE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             X2STAMP(1);

@@ -24,17 +24,17 @@ def amd():
     return rnnt_amd
 
 
-@pytest.mark.parametrize("variant", ["dw_only", "dw_dhidden", "all", "dw_8w", "fwd_2wg"])
+@pytest.mark.parametrize("variant", ["dw_only", "dw_dhidden", "all", "dw_8w", "dw_p16", "fwd_2wg"])
 @pytest.mark.parametrize("shape", [(2, 9, 4, 128, 128), (3, 23, 19, 256, 384), (2, 40, 33, 512, 1024), (2, 13, 20, 1024, 256),
                                    (3, 21, 9, 640, 128), (2, 130, 50, 512, 256)])
 def test_x2_kernels_in_isolation(amd, variant, shape):
     """With RNNT_VARIANT_X3_FP32_FWD | _DH only k_dw_x2 runs (forward and dHidden on the fp32 route's kernels, k_x2_make_hidden
     / k_x2_split_g in between), with _FWD alone k_dhidden_x2 + k_dw_x2, without a variant all three — each against the fp64
-    oracle at the fp32 tolerances.  dw_8w: dW as eight waves per workgroup (k_dw_x2<8>, two per SIMD); fwd_2wg: the forward as two
+    oracle at the fp32 tolerances.  dw_8w: dW as eight waves per workgroup (k_dw_x2<8>, two per SIMD); dw_p16: dW on v_mfma_f32_16x16x32_f16 (k_dw_x2p); fwd_2wg: the forward as two
     4-wave workgroups per CU (k_joint_fwd_x2d) — both measured equal to the defaults and kept behind their variants."""
     e = amd.engine
     var = {"dw_only": e.VARIANT_X3_FP32_FWD | e.VARIANT_X3_FP32_DH, "dw_dhidden": e.VARIANT_X3_FP32_FWD, "all": 0,
-           "dw_8w": e.VARIANT_X2_DW_8W, "fwd_2wg": e.VARIANT_X2_FWD_2WG}[variant]
+           "dw_8w": e.VARIANT_X2_DW_8W, "fwd_2wg": e.VARIANT_X2_FWD_2WG, "dw_p16": e.VARIANT_X2_DW_P16}[variant]
     B, T, U, H, V = shape
     d = make_inputs(B, T, U, H, V, seed=sum(shape))
     g = _dev(d)
