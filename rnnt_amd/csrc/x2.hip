@@ -236,7 +236,9 @@ struct X2Frag { u32x2 lo[4], hi[4]; };  // 4 tiles: cells 0-3 / 4-7 of a lane's 
 // LDS-DMA issues blocks it — the SIMD's other wave fills with MFMAs.  MEASURED EQUAL (15.5 ms both, cfg2): the kernel is bound by
 // the bytes it stages — 32 KiB per k-step and CU at ~12.6 B/clk/CU (6.8 TB/s over the chip out of L2), the same rate the forward's
 // and dHidden's W streams reach — not by issue stalls.  4 is the default; 8 stays behind RNNT_VARIANT_X2_DW_8W.
-template <int NW>
+// PARTH (H % 256 == 128: the last h block is half empty — H = 640): the waves of the dead 128-column half run no product MFMAs and the
+// dead hidden tile's DMAs are requested past their buffer's range (no bytes moved; the instruction and its vmcnt stay).
+template <int NW, bool PARTH = false>
 __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
 {
     constexpr int WN = NW / 2;      // waves along h
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
         const int otile = NW == 8 ? wave >> 1 : wave;
         const bool is_g = otile < 2;
         int col0 = (is_g ? vb : hb) * 256 + 128 * (otile & 1);
+        const bool dead_tile = PARTH && !is_g && col0 >= H;  // (wave-uniform)
         if (col0 >= (is_g ? V : H)) col0 = 0;  // tile beyond the matrix: never stored, read something valid
         const char *pbase[2];  // plane p of this wave's operand: base pointer (wave-uniform), row stride in bytes
         long rstride;
@@ -307,8 +310,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
             const int jg = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
             // interleaved planes (G): chunk jg of the plane is 16 bytes at 128*(jg>>2) + 16*(jg&3)
             const int cb = is_g ? 128 * (jg >> 2) + 16 * (jg & 3) : 16 * jg;
-            soff[i] = (int)((4 * i + (lane >> 4)) * rstride) + cb;
+            soff[i] = dead_tile ? 0x7ffffff0 : (int)((4 * i + (lane >> 4)) * rstride) + cb;
         }
+        const bool live_n = !PARTH || hb * 256 + wn * 32 * QN < H;  // this wave's h columns exist (wave-uniform)
         long row_first = 0;  // first cell of the range being walked
         // ---- transposed fragment reads.  Fragment of 32-column tile m: lane (g = lane>>4, q = (lane&15)>>2,
         // p = lane&3) reads rows 8(g>>1) + 4sec + q at chunk 4m + 2(g&1) + (p>>1), +8(p&1) bytes, sec = 0,1.
@@ -382,8 +386,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
                 }
 #pragma unroll
                 for (int qm = 0; qm < 4; ++qm) {
+                    if (live_n) {
 #pragma unroll
-                    for (int qn = 0; qn < QN; ++qn) acc[qm][qn] = x2_mfma(fa[qm], fb[qn], acc[qm][qn]);
+                        for (int qn = 0; qn < QN; ++qn) acc[qm][qn] = x2_mfma(fa[qm], fb[qn], acc[qm][qn]);
+                    }
                     if (qm == 0 && CNT >= 1) dma_piece(X2Int<N0>{});
                     if (qm == 1 && CNT >= 2) dma_piece(X2Int<N0 + (CNT >= 2 ? 1 : 0)>{});
                     if (qm == 3 && CNT == 3) dma_piece(X2Int<N0 + (CNT == 3 ? 2 : 0)>{});
@@ -816,10 +822,12 @@ void launch_dw_x2(const X3Args &a, hipStream_t st)
         (void)hipFuncSetAttribute((const void *)k_dw_x2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
         (void)hipFuncSetAttribute((const void *)k_dw_x2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
         (void)hipFuncSetAttribute((const void *)k_dw_x2p, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
+        (void)hipFuncSetAttribute((const void *)k_dw_x2<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
         if (dev >= 0) attr_set[dev] = true;
     }
     if (a.flags & RNNT_VARIANT_X2_DW_P16) { hipLaunchKernelGGL(k_dw_x2p, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a); return; }
     if (a.flags & RNNT_VARIANT_X2_DW_8W) hipLaunchKernelGGL(k_dw_x2<8>, dim3(tiles * a.n_split), dim3(512), 4 * XW2_TILE, st, a);
+    else if (a.H % 256 != 0) hipLaunchKernelGGL((k_dw_x2<4, true>), dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
     else hipLaunchKernelGGL(k_dw_x2<4>, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
 }
 
@@ -884,7 +892,10 @@ size_t x2_wpack_dh_bytes(int H, int V) { return (size_t)((H + 511) / 512) * (V /
 #define XG2_WSLOT 32768   // one k-step of W: 2 planes x 16 tiles x 1 KiB
 #define XG2_XSLOT 8192    // one k-step of G fragments: 4 M tiles x 2 planes x 1 KiB
 #define XG2_NW 3          // W ring slots: the DMAs of k-step c+2 are issued during k-step c (as in k_joint_fwd_x2)
-template <bool FIRST>
+// PART: the pass covers fewer than 512 columns (H = 640: the second pass has 128; H < 512): the dead 128-column groups run no MFMAs
+// and their W pieces are requested past the pack's range (an out-of-range LDS-DMA moves no bytes and writes zeros: the instruction
+// stays, so every vmcnt stays a count) — a pass then costs what its live columns cost plus the G stream.
+template <bool FIRST, bool PART>
 __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
 {
     // [0, 96 KiB): W ring, 3 slots;  [96, 112 KiB): G exchange, 2 slots.  The epilogue reuses the W ring.
@@ -899,6 +910,7 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
     len_tu_uniform(a.logit_lens, a.target_lens, b, a.T, a.U1, Tb, Ub);
     const int t0 = tt * XG2_BT, u0 = ub * XG2_BU;
     const int VC = V / 16;
+    const int ngrp = PART ? (H - 512 * hp) / 128 : 4;  // live 128-column groups of this pass (H % 128 == 0)
     if (FIRST) X2_CLOCK_STAMP(128 + 108);  // (one tile of ~0.1 ms: 1e-4 resolution at the 100 MHz reference)
 
     // ---- producer role: M tile `wave`, row i = cell (pt, pu)
@@ -1034,7 +1046,8 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
     };
     auto wdma = [&](int c, int slot, int n) {  // piece n (0..7) of this wave's share of W k-step c -> ring slot `slot`
         const int cc = c < VC ? c : VC - 1;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + slot * XG2_WSLOT + (wave * 8 + n) * 1024), 16, wvo,
+        const int vo = (!PART || (((wave * 8 + n) & 15) >> 2) < ngrp) ? wvo : 0x7ffffff0;  // (piece = plane (pc >> 4), tile pc & 15 = group (pc & 15) >> 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_vptr)(s_dh + slot * XG2_WSLOT + (wave * 8 + n) * 1024), 16, vo,
                                                  (cc * 32 + wave * 8 + n) * 1024, 0, 0);
     };
 
@@ -1094,8 +1107,10 @@ __global__ __launch_bounds__(256, 1) void k_dhidden_x2(X3Args a, const int hp)
                 constexpr int PA = decltype(pa_c)::value, BLK = decltype(blk_c)::value;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    acc[0][q] = x2_mfma(af[0][PA], bcur[q], acc[0][q]);
-                    acc[1][q] = x2_mfma(af[1][PA], bcur[q], acc[1][q]);
+                    if (!PART || 2 * wn + (q >> 2) < ngrp) {  // (wave-uniform)
+                        acc[0][q] = x2_mfma(af[0][PA], bcur[q], acc[0][q]);
+                        acc[1][q] = x2_mfma(af[1][PA], bcur[q], acc[1][q]);
+                    }
                     if (BLK == 0) {
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[q]) : "v"(ws), "n"(16384 + q * 1024));
                         if (prod_on) produce_slice(P, rawn, c + 1, q);
@@ -1240,13 +1255,19 @@ void launch_dhidden_x2(const X3Args &a, hipStream_t st)
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
     const int lds = XG2_NW * XG2_WSLOT + 2 * XG2_XSLOT;
     if (dev < 0 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)k_dhidden_x2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (dev >= 0) attr_set[dev] = true;
     }
     dim3 grid(a.n_ublk16, (a.T + XG2_BT - 1) / XG2_BT, a.B);
-    hipLaunchKernelGGL(k_dhidden_x2<true>, grid, dim3(256), lds, st, a, 0);
-    for (int hp = 1; hp * 512 < a.H; ++hp) hipLaunchKernelGGL(k_dhidden_x2<false>, grid, dim3(256), lds, st, a, hp);
+    if (a.H < 512) hipLaunchKernelGGL((k_dhidden_x2<true, true>), grid, dim3(256), lds, st, a, 0);
+    else hipLaunchKernelGGL((k_dhidden_x2<true, false>), grid, dim3(256), lds, st, a, 0);
+    for (int hp = 1; hp * 512 < a.H; ++hp) {
+        if (a.H - 512 * hp < 512) hipLaunchKernelGGL((k_dhidden_x2<false, true>), grid, dim3(256), lds, st, a, hp);
+        else hipLaunchKernelGGL((k_dhidden_x2<false, false>), grid, dim3(256), lds, st, a, hp);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
