@@ -69,22 +69,16 @@ class RNNTModel(torch.nn.Module):
         return hasattr(self.joint, "text_ln") or O == H
 
     def _decode_tables(self):
-        """The persistent decode's model tables (engine.greedy_decode_tables), cached until a parameter they are built from changes
-        (its storage or its version counter: optimizer steps, load_state_dict, .to(...))."""
+        """The persistent decode's model tables (engine.greedy_decode_tables: conv2's pack, conv1 as tap tables, the folded text_ln) built
+        from the parameters AS THEY ARE NOW, on the current stream.  Nothing is cached on the module: the engine's own optimizer
+        (rnnt_amd.optim.AdamW) and replays of a captured training step update parameters through raw pointers, which no version counter
+        sees, so a cache keyed on tensor identity went stale between the reference flow's evaluations (rnnt/train.py:165-201).  A build is
+        ~0.13 ms; greedy_decode_many shares one build between all utterances of a call, greedy_decode lets the launch rebuild in place."""
         from . import engine
         tl = getattr(self.joint, "text_ln", None)
-        src = list(self.predictor._params()) + ([tl.weight, tl.bias] if tl is not None else [])
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in src) + (self.joint.joint_ln.in_features,)
-        cached = getattr(self, "_decode_tables_cache", None)
-        if cached is None or cached[0] != key:
-            tables = engine.greedy_decode_tables(self.predictor._params(), float(self.predictor.output_layer_norm.eps),
-                                                 tl.weight if tl is not None else None, tl.bias if tl is not None else None,
-                                                 self.joint.joint_ln.in_features)
-            cached = (key, tables, torch.cuda.Event())
-            cached[2].record()  # other streams wait for the build before reading the tables
-            object.__setattr__(self, "_decode_tables_cache", cached)
-        torch.cuda.current_stream().wait_event(cached[2])
-        return cached[1]
+        return engine.greedy_decode_tables(self.predictor._params(), float(self.predictor.output_layer_norm.eps),
+                                           tl.weight if tl is not None else None, tl.bias if tl is not None else None,
+                                           self.joint.joint_ln.in_features)
 
     @torch.no_grad()
     def greedy_decode(self, mel_features: torch.Tensor, mel_feature_lens: torch.Tensor,
@@ -121,7 +115,7 @@ class RNNTModel(torch.nn.Module):
                 persistent = engine.greedy_decode_persistent_supported(frames.shape[0], S, E, self.predictor.linear.weight.shape[0],
                                                                        frames.shape[1], self.joint.joint_ln.weight.shape[0], tl is not None)
             if persistent:
-                state, toks = engine.greedy_decode_persistent(*args, max_per_frame=10, tables=self._decode_tables())
+                state, toks = engine.greedy_decode_persistent(*args, max_per_frame=10)  # tables rebuilt inside the call, from the live weights
             else:
                 state, toks = engine.greedy_decode_loop(*args, max_per_frame=10,
                                                         scan_frames=max(1, min(int(scan_frames) if scan_frames > 0 else 64, 128)))
@@ -213,6 +207,7 @@ class RNNTModel(torch.nn.Module):
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         n_par = max(1, min(int(concurrency) if concurrency else 8, cus // groups, len(mels)))
         cur = torch.cuda.current_stream(dev)
+        tables = self._decode_tables()  # one build per call, on `cur`; every side stream waits for `cur` before its first launch
         streams = [torch.cuda.Stream(device=dev) for _ in range(n_par)]
         pending = []
         for i, mel in enumerate(mels):
@@ -228,7 +223,7 @@ class RNNTModel(torch.nn.Module):
                     frames, self.predictor._params(), float(self.predictor.output_layer_norm.eps),
                     tl.weight if tl is not None else None, tl.bias if tl is not None else None,
                     self.joint.joint_ln.weight, self.joint.joint_ln.bias, self.joint.blank_idx, max_length, max_per_frame=10,
-                    tables=self._decode_tables())
+                    tables=tables)
             pending.append((state, mel))
         for st in streams:
             st.synchronize()

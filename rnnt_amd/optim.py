@@ -175,6 +175,10 @@ class AdamW(torch.optim.Optimizer):
                 raise RuntimeError("rnnt_amd.optim.AdamW does not support sparse gradients")
             dev = _check_group(ps, "parameters")
             _check_group(gs, "gradients")
+            # the kernels write parameters and moments through raw pointers: tell autograd (tensors saved for a pending backward, and
+            # anything else keyed on `_version`) that they changed in place, as torch's own in-place optimizer ops do.  (A REPLAY of a
+            # captured step cannot do this: consumers must not cache on `_version` alone — RNNTModel's decode tables do not.)
+            torch.autograd.graph.increment_version(ps)
             if self.capturable:
                 self._step_capturable(lib, gi, group, ps, gs, dev, total)
                 continue

@@ -160,3 +160,83 @@ def assert_close_digest(name, got, dig, seed, rtol=GRAD_RTOL):
     assert ep <= rtol * amax * np.sqrt(n) + GRAD_ATOL, f"{name}: projections off by {ep:.3e} > {rtol * amax * np.sqrt(n):.3e}"
     assert abs(float(mine["norm"]) - float(dig["norm"])) <= rtol * float(dig["norm"]) + GRAD_ATOL, name + ": 2-norm"
     return es / max(amax, 1e-300), ep / max(amax * np.sqrt(n), 1e-300)
+
+
+# ---- greedy-decode cases (tests/golden/decode_*.npz; tests/golden/make_golden_decode.py) --------------------------------
+# name: V (= num_symbols = num_classes), E, O, H, fa, ft (audio_ln / text_ln inputs, -1 = none), T frames, max_lengths,
+#       w_scale (joint_ln.weight multiplier: spreads the logits so that top-2 gaps sit far above rounding), store (arrays in
+#       the fixture; False: regenerated from the seed below and pinned by SHA-256 — the reference's widths are 16-30 MB of weights)
+DECODE_CASES = {
+    "decode_small": dict(V=32, E=48, O=64, H=64, fa=-1, ft=-1, T=75, max_lengths=(60, 9), w_scale=12.0, store=True),
+    "decode_small_proj": dict(V=300, E=36, O=56, H=64, fa=40, ft=56, T=45, max_lengths=(60, 9), w_scale=20.0, store=True),
+    "decode_cap": dict(V=32, E=48, O=64, H=64, fa=-1, ft=-1, T=14, max_lengths=(200, 37), w_scale=12.0, store=True,
+                       want_cap=True),  # blank almost never wins: every frame runs into the 10-symbols-per-frame cap
+    "decode_wide_vocab": dict(V=4000, E=64, O=192, H=192, fa=-1, ft=-1, T=90, max_lengths=(60, 9), w_scale=30.0, store=False),
+    "decode_ref_widths": dict(V=1024, E=512, O=1024, H=1024, fa=-1, ft=-1, T=200, max_lengths=(200, 25), w_scale=30.0,
+                              store=False),  # config/basic_sp_convjs_fullcausal.yaml:20-25,60-65
+    "decode_ref_widths_proj": dict(V=1024, E=512, O=1024, H=1024, fa=1024, ft=1024, T=120, max_lengths=(200, 25), w_scale=30.0,
+                                   store=False),  # config/basic_sp_conv.yaml:65-70 (audio_ln + text_ln enabled)
+}
+
+
+def decode_case_arrays(spec, seed, blank_bias):
+    """(frames [T, C], predictor state dict, joint state dict) of a decode case, float32, from numpy's PCG64 stream `seed`:
+    torch-default-like scales (Linear / Conv1d: U(+-1/sqrt(fan_in)); embedding N(0,1); LayerNorm affine 1 + 0.2 N, 0.2 N)."""
+    rng = np.random.default_rng(seed)
+    V, E, O, H, fa, ft = (spec[k] for k in ("V", "E", "O", "H", "fa", "ft"))
+
+    def uni(shape, fan_in):
+        k = 1.0 / np.sqrt(fan_in)
+        return rng.uniform(-k, k, shape).astype(np.float32)
+
+    def nrm(shape, scale=1.0, shift=0.0):
+        return (shift + scale * rng.standard_normal(shape)).astype(np.float32)
+
+    pred = {"embedding.weight": nrm((V, E)),
+            "input_layer_norm.weight": nrm(E, 0.2, 1.0), "input_layer_norm.bias": nrm(E, 0.2),
+            "conv1.conv.weight": uni((E, E, 3), 3 * E), "conv1.conv.bias": uni(E, 3 * E),
+            "conv2.conv.weight": uni((E, E, 5), 5 * E), "conv2.conv.bias": uni(E, 5 * E),
+            "linear.weight": uni((O, E), E), "linear.bias": uni(O, E),
+            "output_layer_norm.weight": nrm(O, 0.2, 1.0), "output_layer_norm.bias": nrm(O, 0.2)}
+    joint = {}
+    if fa > 0:
+        joint["audio_ln.weight"], joint["audio_ln.bias"] = uni((H, fa), fa), uni(H, fa)
+    if ft > 0:
+        assert ft == O
+        joint["text_ln.weight"], joint["text_ln.bias"] = uni((H, ft), ft), uni(H, ft)
+    joint["joint_ln.weight"] = (uni((V, H), H) * np.float32(spec["w_scale"])).astype(np.float32)
+    joint["joint_ln.bias"] = uni(V, H)
+    joint["joint_ln.bias"][V - 1] += np.float32(blank_bias)
+    frames = nrm((spec["T"], fa if fa > 0 else H))
+    return frames, pred, joint
+
+
+def sha256_of_arrays(*dicts_or_arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for d in dicts_or_arrays:
+        items = sorted(d.items()) if isinstance(d, dict) else [("", d)]
+        for k, a in items:
+            a = np.ascontiguousarray(a)
+            h.update(k.encode() + str(a.dtype).encode() + str(a.shape).encode() + a.tobytes())
+    return h.hexdigest()
+
+
+def load_decode_case(golden_dir, name):
+    """-> dict(frames, pred_sd, joint_sd, tokens {max_length: list}, margins {max_length: array}, spec).  Cases stored as seed +
+    SHA-256 regenerate their arrays and fail loudly if numpy's stream ever changes."""
+    import os
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    spec = DECODE_CASES[name]
+    seed, bias = int(z["seed"]), float(z["blank_bias"])
+    if spec["store"]:
+        frames = z["frames"]
+        pred = {k[6:].replace("__", "."): z[k] for k in z.files if k.startswith("pred__")}
+        joint = {k[7:].replace("__", "."): z[k] for k in z.files if k.startswith("joint__")}
+    else:
+        frames, pred, joint = decode_case_arrays(spec, seed, bias)
+    got = sha256_of_arrays(frames, pred, joint)
+    assert got == str(z["sha256"]), f"{name}: inputs regenerated from seed {seed} do not hash to the fixture's SHA-256"
+    toks = {int(m): z[f"tokens_ml{int(m)}"].tolist() for m in z["max_lengths"]}
+    margins = {int(m): z[f"margins_ml{int(m)}"] for m in z["max_lengths"]}
+    return dict(frames=frames, pred_sd=pred, joint_sd=joint, tokens=toks, margins=margins, spec=spec)
