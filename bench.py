@@ -137,7 +137,6 @@ def self_launch(n):
     (SIGTERM / SIGINT, e.g. the driver's timeout) takes its ranks with it — none is left blocked in a
     collective holding a GPU and the rendezvous port."""
     import signal
-    import socket
     import subprocess
     have = torch.cuda.device_count()
     single = os.environ.get("BENCH_SINGLE_DEVICE") == "1"  # rehearsal: every rank on cuda:0
@@ -146,10 +145,11 @@ def self_launch(n):
                                    "benchmark fewer GPUs than asked for", "hipGetDeviceCount": have,
                           "n_gpus_requested": n}), flush=True)
         raise SystemExit(3)
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
+    # rendezvous of the self-launched ranks: a FILE store in a fresh private directory (one node, one file system) — no TCP port to pick.
+    # ("bind to port 0, read the number, close, hand it to the children" leaves a window in which anything on the box — RCCL's own
+    # bootstrap sockets included — can take the port before rank 0's store binds it.)
+    import tempfile
+    rdzv_dir = tempfile.mkdtemp(prefix="rnnt_bench_rdzv_")
     procs = []
 
     def stop_ranks(grace=5.0):
@@ -171,8 +171,8 @@ def self_launch(n):
     rc = 0
     try:
         for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), BENCH_INIT_FILE=os.path.join(rdzv_dir, "store"),
+                       HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=None if r == 0 else subprocess.DEVNULL))
         live = list(procs)
@@ -191,6 +191,8 @@ def self_launch(n):
         stop_ranks()
         for sig, h in old.items():
             signal.signal(sig, h)
+        import shutil
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
     raise SystemExit(rc)
 
 
@@ -236,14 +238,31 @@ def main():
     # with a single rank, so the RCCL calls can be exercised on a one-GPU box
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
+        # rendezvous: the launcher's (torchrun / the driver: MASTER_ADDR + MASTER_PORT in the environment, init_method env://); a file store
+        # for ranks this script launched itself (BENCH_INIT_FILE, self_launch) and for a single forced rank with no launcher at all
+        # (BENCH_FORCE_DIST=1: a private temporary file — a one-rank group needs no TCP port, and a fixed default port or one picked by
+        # bind-close-reuse can be taken by the time the store binds it)
+        init_file = os.environ.get("BENCH_INIT_FILE")
+        own_dir = None
+        if init_file is None and "MASTER_PORT" not in os.environ:
+            if world != 1:
+                raise SystemExit("WORLD_SIZE > 1 without MASTER_PORT or BENCH_INIT_FILE: launch through torchrun or `bench.py --gpus N`")
+            import tempfile
+            own_dir = tempfile.mkdtemp(prefix="rnnt_bench_rdzv_")
+            init_file = os.path.join(own_dir, "store")
+        kw = dict(init_method="file://" + init_file, rank=rank, world_size=world) if init_file else {}
+        if not init_file:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=device, **kw)  # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
+        if own_dir is not None:
+            import atexit
+            import shutil
+            atexit.register(shutil.rmtree, own_dir, ignore_errors=True)
 
     import rnnt_amd
     from rnnt_amd import engine
@@ -341,8 +360,26 @@ def main():
         ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
         m = ts[len(ts) // 2]
         tf = 6.0 * H * V * Bl * T * (U + 1) / (m * 1e-3) / 1e12
+        loss_r = float(outs[0].double().sum().item() * scale)
+        # the route's own kernel roofline (round-5 verdict item 7): its three GEMM stages timed one by one (HIP events on the launch
+        # stream, mean of `reps` back-to-back launches), the slowest of them priced at 2 H V flop per cell against the route's peak
+        reps = max(3, n // 2)
+        gemm_ms = {}
+        for s_idx, name in ((1, "joint_fwd_gemm"), (4, "dhidden_gemm"), (6, "dw_gemm")):
+            engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s_idx, dtype=dt)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                engine.joint_loss_fwd_bwd(enc, pred, W, bias, targets, ll, tl, V - 1, scale, outs=outs, stage=s_idx, dtype=dt)
+            e1.record(); e1.synchronize()
+            gemm_ms[name] = e0.elapsed_time(e1) / reps
+        dom_r = max(gemm_ms, key=gemm_ms.get)
+        ach_r = 2.0 * H * V * Bl * T * (U + 1) / (gemm_ms[dom_r] * 1e-3) / 1e12
         return {"ms_per_step": m, "value": B * T * U / (m * 1e-3), "unit": "cells/s", "steps": n, "arith": arith, "path_tflops": tf,
-                "peak": peak, "frac": tf / peak, "loss": float(outs[0].double().sum().item() * scale),
+                "peak": peak, "frac": tf / peak, "loss": loss_r,
+                "roofline": {"bound": "mfma", "kernel": dom_r, "ms": gemm_ms[dom_r], "achieved": ach_r, "peak": peak, "unit": "TFLOP/s",
+                             "frac": ach_r / peak, "gemm_stage_ms": gemm_ms,
+                             "note": "2*H*V flop per cell per GEMM launch / HIP-event time of that stage"},
                 "timing": f"hipEventElapsedTime per step, median of {n}, same process and inputs as the headline"}
 
     exact_fp32 = route_bf16x3 = None

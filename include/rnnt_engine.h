@@ -90,21 +90,9 @@ void rnnt_engine_set_debug(void *buf);
  * NOT bit-identical to the default bf16x3 kernels (different summation), same tolerance. */
 #define RNNT_VARIANT_X3_FP32_FWD 4096       /* forward GEMM + hidden by the fp32 kernel, then k_x3_make_hidden */
 #define RNNT_VARIANT_X3_FP32_DH 8192        /* dHidden + G by the fp32 kernels, then k_x3_split_g (needs _FWD too) */
-/* RNNT_DTYPE_F32_BF16X3 only: the forward in its two-waves-per-SIMD forms (k_joint_fwd_x3d, round 4: each wave owns 32
- * rows x 256 columns, the A operand never leaves its registers) instead of the default k_joint_fwd_x3 (one 512-register
- * wave per SIMD).  Measured SLOWER than the default: kept as the record of that experiment and as a
- * second, independently written forward that tests compare.  Same products, different summation order inside a dot
- * product: same tolerance, not bit-identical. */
-#define RNNT_VARIANT_X3_FWD_2WG 16384       /* two 4-wave workgroups per CU, 128-cell tiles */
-#define RNNT_VARIANT_X3_FWD_8W 65536        /* one 8-wave workgroup per CU, 256-cell tiles */
-#define RNNT_VARIANT_X2_FWD_2WG 1048576      /* RNNT_DTYPE_F32_F16X2 only: the forward as two 4-wave workgroups per CU (k_joint_fwd_x2d: A in registers, 256-column passes) */
-#define RNNT_VARIANT_X2_DW_P16 2097152       /* RNNT_DTYPE_F32_F16X2 only: dW on v_mfma_f32_16x16x32_f16 (k_dw_x2p: a k = 32 MFMA spans two 16-cell ring stages) */
-#define RNNT_VARIANT_X2_DW_8W 524288        /* RNNT_DTYPE_F32_F16X2 only: dW as 8 waves per workgroup (two per SIMD, k_dw_x2<8>) instead of the default 4: measured equal (15.5 ms), kept for the record */
-#define RNNT_VARIANT_X3_FWD_Z 262144        /* k_joint_fwd_x3z: one wave per SIMD with two M tiles (256 x 256 tiles, A in registers) */
-/* RNNT_DTYPE_F32_BF16X3 only: dW on v_mfma_f32_16x16x32_bf16 with two of the six products per MFMA (k_dw_x3p, round 4)
- * instead of the default k_dw_x3 (v_mfma_f32_32x32x16_bf16).  Measured equal in time: kept as the record of
- * that experiment.  Same products, different summation order. */
-#define RNNT_VARIANT_X3_DW_P16 131072
+/* Bits 14 and up name kernels of the DIAGNOSTIC library only (rnnt_amd/csrc/lab/rnnt_engine_lab.h, tools/build_lab.sh):
+ * librnnt_engine.so answers them with RNNT_ERR_UNSUPPORTED. */
+#define RNNT_VARIANT_LAB_MASK 0x7fffc000
 
 /* Diagnostic queries (0/1: predicted resident forward-kernel workgroups per CU). */
 int rnnt_engine_debug_query(int what);
@@ -263,7 +251,8 @@ int rnnt_engine_adamw_step_dev(int n_tensors, void *const *params, const void *c
  * one MFMA GEMM per tap.  All pointers fp32 device pointers, 16-byte aligned; E % 4 == 0, O % 4 == 0.
  *   ids [B,U1] int64 (as the reference passes them, rnnt/model.py:20-21); out [B,U1,O];
  *   keep1 / keep2 [B,U1,E] bytes: dropout keep masks drawn by the caller (NULL = eval mode), kept
- *   values are scaled by 1/(1-dropout_p);  ln_eps: torch.nn.LayerNorm's eps (1e-5);
+ *   values are scaled by 1/(1-dropout_p);  ln_in_eps / ln_out_eps: the eps of input_layer_norm / output_layer_norm
+ *   (torch.nn.LayerNorm's default: 1e-5 each);
  *   `saved`: caller-owned buffer (rnnt_engine_conv_predictor_saved_bytes) the forward fills and the
  *   backward of the SAME call reads; `g`: where each parameter's gradient is written (same field
  *   order as the parameters; every gradient is overwritten, not accumulated).
@@ -280,7 +269,7 @@ typedef struct rnnt_conv_predictor_params {
 int rnnt_engine_conv_predictor_saved_bytes(int B, int U1, int S, int E, int O, size_t *out);
 int rnnt_engine_conv_predictor_fwd(const int64_t *ids, int B, int U1, int S, int E, int O,
                                    const rnnt_conv_predictor_params *p, const uint8_t *keep1,
-                                   const uint8_t *keep2, float dropout_p, float ln_eps, float *out,
+                                   const uint8_t *keep2, float dropout_p, float ln_in_eps, float ln_out_eps, float *out,
                                    void *saved, size_t saved_bytes, void *stream);
 int rnnt_engine_conv_predictor_bwd(const int64_t *ids, int B, int U1, int S, int E, int O,
                                    const rnnt_conv_predictor_params *p, const uint8_t *keep1,

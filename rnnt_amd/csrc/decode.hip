@@ -465,6 +465,9 @@ typedef unsigned long long dp_u64;
 #endif
 #define DP_FRAMES 16
 #define DP_TOKS 2048
+#define DP_FACTOR_RANGE 30.f      // |x| up to which exp(2 x) is used as a factor of the hidden value (k_dp_exp_frames below)
+#define DP_CODE_FRAME_RANGE 10   // state[7]: an audio frame, or (11) a text vector, beyond it — not a decode, the caller takes the other loop
+#define DP_CODE_TEXT_RANGE 11
 #ifndef DP_SPIN_LIMIT
 #define DP_SPIN_LIMIT (1 << 21)  // polls (~1.5 us each) before a sweep gives up
 #endif
@@ -643,6 +646,7 @@ __global__ __launch_bounds__(256) void k_dec_persist(DecPersistArgs a)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dpt0)::"memory");
 #endif
 
+    if (__hip_atomic_load(a.state + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) done = 1;  // k_dp_exp_frames: a frame beyond the factored form's range
     for (it = 1; it <= a.max_iters && !done; ++it) {
         // ---- exp(2 enc) fragments: lane i16 holds the frame of [t, t + 16) that is i16 mod 16 (frames past T-1 repeat the last; the
         // bookkeeping ignores them); only lanes whose frame changed load
@@ -794,7 +798,8 @@ __global__ __launch_bounds__(256) void k_dec_persist(DecPersistArgs a)
                 rstd = rsqrtf(dp_wave_sum(m2) / O + a.eps);
                 for (int h = tid; h < H; h += 256) {  // text = rstd (q - mean r) + c
                     const float x = rstd * (s_y[h] - mean * s_g[h]) + s_b[h];
-                    s_P[h] = __builtin_amdgcn_exp2f(fminf(fmaxf(x, -30.f), 30.f) * (2.0f * RNNT_LOG2E));
+                    if (!(fabsf(x) <= DP_FACTOR_RANGE)) s_fail = 2;
+                    s_P[h] = __builtin_amdgcn_exp2f(fminf(fmaxf(x, -DP_FACTOR_RANGE), DP_FACTOR_RANGE) * (2.0f * RNNT_LOG2E));
                 }
             } else {  // text = LN(z) gamma + beta   (rnnt/predictor.py:229; O == H)
                 float s1 = 0.f;
@@ -809,10 +814,12 @@ __global__ __launch_bounds__(256) void k_dec_persist(DecPersistArgs a)
                 rstd = rsqrtf(dp_wave_sum(s2) / H + a.eps);
                 for (int h = tid; h < H; h += 256) {
                     const float x = (s_y[h] - mean) * rstd * s_g[h] + s_b[h];
-                    s_P[h] = __builtin_amdgcn_exp2f(fminf(fmaxf(x, -30.f), 30.f) * (2.0f * RNNT_LOG2E));
+                    if (!(fabsf(x) <= DP_FACTOR_RANGE)) s_fail = 2;
+                    s_P[h] = __builtin_amdgcn_exp2f(fminf(fmaxf(x, -DP_FACTOR_RANGE), DP_FACTOR_RANGE) * (2.0f * RNNT_LOG2E));
                 }
             }
             __syncthreads();
+            if (s_fail) { code = DP_CODE_TEXT_RANGE; break; }  // every workgroup computes the same text vector: all of them leave here
             DP_T(6);
         }
         // ---- hand-off 3: the scan.  Workgroup g owns vocabulary blocks g, g + G, ... of 16 entries
@@ -995,19 +1002,27 @@ __global__ __launch_bounds__(256) void k_dec_persist(DecPersistArgs a)
 #undef s_fail
 }
 
-// exp(2 x) of every audio frame, clamped to |x| <= 30 (tanh(30 + p) is 1 to fp32 for every p > -20; the product with
-// exp(2 text), clamped alike, stays finite or saturates to 0 / inf, both of which give the right -1 / +1)
-__global__ __launch_bounds__(256) void k_dp_exp_frames(const float *__restrict__ frames, long st, int T, int H, float *__restrict__ out)
+// exp(2 x) of every audio frame.  tanh(e + p) = 1 - 2 / (1 + exp(2 e) exp(2 p)) is exact while neither factor leaves fp32's range:
+// |x| <= DP_FACTOR_RANGE.  A frame (here) or a text vector (in the loop) beyond it, or non-finite, is NOT clamped into a wrong answer
+// (enc = 40, text = -35: the clamped factors multiply to tanh(0), the truth is tanh(5)) — the decode reports it in state[7]
+// (DP_CODE_*_RANGE) and leaves, and the caller runs the kernel-per-layer loop, which takes tanh of the SUM (round-5 advice).
+__global__ __launch_bounds__(256) void k_dp_exp_frames(const float *__restrict__ frames, long st, int T, int H, float *__restrict__ out,
+                                                       int32_t *__restrict__ state)
 {
     const long n4 = (long)T * (H / 4);
+    bool bad = false;
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n4; j += (long)gridDim.x * 256) {
         const long t = j / (H / 4), h = 4 * (j - t * (H / 4));
         const f32x4 x = *(const f32x4 *)(frames + t * st + h);
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = __builtin_amdgcn_exp2f(fminf(fmaxf(x[e], -30.f), 30.f) * (2.0f * RNNT_LOG2E));
+        for (int e = 0; e < 4; ++e) {
+            bad |= !(fabsf(x[e]) <= DP_FACTOR_RANGE);  // (true for NaN as well)
+            y[e] = __builtin_amdgcn_exp2f(fminf(fmaxf(x[e], -DP_FACTOR_RANGE), DP_FACTOR_RANGE) * (2.0f * RNNT_LOG2E));
+        }
         *(f32x4 *)(out + t * H + h) = y;
     }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) __hip_atomic_store(state + 7, DP_CODE_FRAME_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // XE[s] = LN(embedding[s]) gamma + beta for every symbol (rnnt/predictor.py:214-215)
@@ -1130,17 +1145,29 @@ static DecPersistLayout dec_persist_layout(int T, int S, int E, int O, int H, in
 }
 size_t dec_persist_workspace_floats(int T, int S, int E, int O, int H, int V, int has_text) { return dec_persist_layout(T, S, E, O, H, V, has_text).total; }
 
-void launch_dec_persist(const DecLoopArgs &a, hipStream_t st)
+// dynamic LDS of k_dec_persist, bytes (100-138 KB: more than the 64 KB default limit, and more than some devices have at all)
+size_t dec_persist_lds_bytes(int E)
+{
+    return ((size_t)8 * E + 6 * 1024 + (size_t)16 * 1024 + 4 * DP_FRAMES * 17 + 64 + 128 + 256 + 2 * DP_FRAMES + 8 * DP_FRAMES + 4 + DP_TOKS) * 4;
+}
+
+// returns hipSuccess, or the error of raising the kernel's dynamic-LDS limit (nothing has been launched then)
+int launch_dec_persist(const DecLoopArgs &a, hipStream_t st)
 {
     const int E = a.E, O = a.O, H = a.H, V = a.V, S = a.S, T = a.T, has_text = a.text_W ? 1 : 0;
     const DecPersistLayout L = dec_persist_layout(T, S, E, O, H, V, has_text);
     const DecTablesLayout TL = dec_tables_layout(S, E, O, H, has_text);
     float *ws = (float *)a.workspace;
     const int G = dec_persist_groups(V);
-    // every polled word starts at tag 0 (iterations count from 1); a kernel, not a memset node (captured calls are kernel chains)
+    // every polled word starts at tag 0 (iterations count from 1): k_dec_init — a kernel, not a memset node (captured calls are kernel chains)
+    const int kf = dec_persist_kf(E, O, H, G, has_text);
+    const size_t lds = dec_persist_lds_bytes(E);
+    const void *kern = kf == 1 ? (const void *)k_dec_persist<1> : kf == 2 ? (const void *)k_dec_persist<2> : (const void *)k_dec_persist<0>;
+    if (const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return (int)e;
+    // (the limit is raised BEFORE anything is enqueued: a refusal leaves the stream untouched)
     const int ngran = (int)(L.eenc - L.gran);
     hipLaunchKernelGGL(k_dec_init, dim3((ngran + 255) / 256), dim3(256), 0, st, a.state, a.tokens, ws + L.gran, ngran, a.blank);
-    hipLaunchKernelGGL(k_dp_exp_frames, dim3(512), dim3(256), 0, st, a.frames, a.frame_stride, T, H, ws + L.eenc);
+    hipLaunchKernelGGL(k_dp_exp_frames, dim3(512), dim3(256), 0, st, a.frames, a.frame_stride, T, H, ws + L.eenc, a.state);
     const float *tb = (const float *)a.tables;
     if (!tb) {
         launch_dec_build_tables(a.p, S, E, O, a.ln_eps, a.text_W, a.text_b, H, ws + L.tables, st);
@@ -1159,13 +1186,8 @@ void launch_dec_persist(const DecLoopArgs &a, hipStream_t st)
     k.S = S; k.E = E; k.O = O; k.H = H; k.V = V; k.blank = a.blank; k.max_length = a.max_length; k.max_per_frame = a.max_per_frame;
     k.has_text = has_text; k.max_iters = a.max_length + T + 2;
     k.state = a.state; k.tokens = a.tokens; k.host_flag = a.host_flag;
-    const int kf = dec_persist_kf(E, O, H, G, has_text);
-    const size_t lds = ((size_t)8 * E + 6 * 1024 + (size_t)16 * 1024 + 4 * DP_FRAMES * 17 + 64 + 128 + 256 + 2 * DP_FRAMES + 8 * DP_FRAMES + 4 + DP_TOKS) * 4;
-    auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, st, k);
-    };
-    if (kf == 1) go(k_dec_persist<1>);
-    else if (kf == 2) go(k_dec_persist<2>);
-    else go(k_dec_persist<0>);
+    if (kf == 1) hipLaunchKernelGGL(k_dec_persist<1>, dim3(G), dim3(256), lds, st, k);
+    else if (kf == 2) hipLaunchKernelGGL(k_dec_persist<2>, dim3(G), dim3(256), lds, st, k);
+    else hipLaunchKernelGGL(k_dec_persist<0>, dim3(G), dim3(256), lds, st, k);
+    return (int)hipSuccess;
 }

@@ -245,8 +245,7 @@ int run_fused(int stages, int variant, const void *enc, const int64_t enc_stride
         return fail(RNNT_ERR_INVALID_ARG, "pointers must be 16-byte aligned (workspace 256)");
     // kernels that were measured equal to (or slower than) the shipped ones live in the diagnostic library only
     // (-DRNNT_LAB, tools/build_lab.sh): the product library refuses their variant bits instead of silently running something else
-    constexpr int lab_only = RNNT_VARIANT_X3_FWD_2WG | RNNT_VARIANT_X3_FWD_8W | RNNT_VARIANT_X3_DW_P16 | RNNT_VARIANT_X3_FWD_Z |
-                             RNNT_VARIANT_X2_DW_8W | RNNT_VARIANT_X2_FWD_2WG | RNNT_VARIANT_X2_DW_P16;
+    constexpr int lab_only = RNNT_VARIANT_LAB_MASK;
 #ifndef RNNT_LAB
     if (variant & lab_only)
         return fail(RNNT_ERR_UNSUPPORTED, "variant 0x%x names a kernel of the diagnostic library (build_variants/lab/librnnt_engine_lab.so, "
@@ -752,6 +751,16 @@ static int dec_persist_check(int T, int S, int E, int O, int H, int V, int has_t
     if (const char *why = dec_persist_refusal(T, S, E, O, H, V, has_text))
         return fail(RNNT_ERR_UNSUPPORTED, "persistent greedy decode: %s (T=%d S=%d E=%d O=%d H=%d V=%d)", why, T, S, E, O, H, V);
     if ((long)T + max_length + 2 >= (1L << 20)) return fail(RNNT_ERR_UNSUPPORTED, "persistent greedy decode: T + max_length must stay below 2^20");
+    // the kernel keeps 100-138 KB in LDS: a device with less (not a gfx950) is "unsupported", so that callers take the kernel-per-layer loop
+    // instead of a failed launch.  Without a device (size queries on a CPU-only host) there is nothing to check against.
+    int dev = 0, lds_max = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess) {
+        if (dec_persist_lds_bytes(E) > (size_t)lds_max)
+            return fail(RNNT_ERR_UNSUPPORTED, "persistent greedy decode needs %zu bytes of LDS per workgroup, the device allows %d",
+                        dec_persist_lds_bytes(E), lds_max);
+    } else {
+        (void)hipGetLastError();
+    }
     return RNNT_OK;
 }
 
@@ -813,7 +822,9 @@ int rnnt_engine_greedy_decode_persistent(const void *frames, int64_t frame_strid
         return fail(RNNT_ERR_UNSUPPORTED, "persistent greedy decode needs %d compute units, the device has %d", dec_persist_groups(V), cus);
     if (tables && ((uintptr_t)tables & 255)) return fail(RNNT_ERR_INVALID_ARG, "tables must be 256-byte aligned");
     a.tables = tables;
-    launch_dec_persist(a, (hipStream_t)stream);
+    if (const int e = launch_dec_persist(a, (hipStream_t)stream))
+        return fail(RNNT_ERR_LAUNCH, "persistent greedy decode: cannot raise the kernel's dynamic LDS limit to %zu bytes: %s",
+                    dec_persist_lds_bytes(E), hipGetErrorString((hipError_t)e));
     return launch_status("rnnt_engine_greedy_decode_persistent");
 }
 

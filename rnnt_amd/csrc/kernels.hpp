@@ -2,6 +2,7 @@
 #pragma once
 #include "common.hpp"
 #include "../../include/rnnt_engine.h"  // rnnt_conv_predictor_params (DecLoopArgs)
+#include "lab/rnnt_engine_lab.h"       // variant bits of the diagnostic library (refused by the product library)
 
 // ---- engine.hip: sets the thread-local error message, returns `code`
 int engine_fail(int code, const char *fmt, ...);
@@ -231,7 +232,8 @@ struct DecPersistArgs {
 int dec_persist_groups(int V);
 const char *dec_persist_refusal(int T, int S, int E, int O, int H, int V, int has_text);  // NULL: supported
 size_t dec_persist_workspace_floats(int T, int S, int E, int O, int H, int V, int has_text);
-void launch_dec_persist(const DecLoopArgs &a, hipStream_t st);  // scan_frames / iterations / init of `a` are not used
+size_t dec_persist_lds_bytes(int E);
+int launch_dec_persist(const DecLoopArgs &a, hipStream_t st);  // hipSuccess, or why the kernel's LDS limit could not be raised (nothing launched);  // scan_frames / iterations / init of `a` are not used
 size_t dec_tables_floats(int S, int E, int O, int H, int has_text);
 void launch_dec_build_tables(const rnnt_conv_predictor_params &p, int S, int E, int O, float ln_eps, const float *text_W, const float *text_b, int H,
                              float *tables, hipStream_t st);

@@ -114,6 +114,8 @@ __device__ __forceinline__ void lattice_sweep(
     // lp pair step k consumes (k counts steps: diagonal d = k for alpha, d = nd-1-k for beta);
     // 0 when the cell or the transition does not exist (the arrays are only written for lattice
     // cells: whatever else they hold must not reach the arithmetic).
+    bool bad = false;
+    double last = NINF;
     auto fetch = [&](int k, float &lb, float &le) {
         const int kk = k < nd ? k : nd - 1;
         const int d = DIR == 0 ? kk : nd - 1 - kk;
@@ -129,6 +131,7 @@ __device__ __forceinline__ void lattice_sweep(
         } else {
             const float vb = lpb[(long)d * U1 + uc];
             const float ve = lpe[(long)d * U1 + uc];
+            bad = bad || (cell && vb != vb);  // a NaN lp_blank inside the lattice -> a NaN cost (see lattice_chain)
             lb = cell ? vb : 0.f;
             le = (cell && u < Ub) ? ve : 0.f;
         }
@@ -157,7 +160,7 @@ __device__ __forceinline__ void lattice_sweep(
         val = valid ? val : NINF;
         cur[u + 1] = val;
         if (k < nd && u < U1) out[(long)d * U1 + u] = val;
-        if (DIR == 1 && k == nd - 1 && u == 0) costs[b] = (float)(-val);
+        if (DIR == 1 && k == nd - 1) last = val;  // (thread u == 0 holds beta[0,0]; the cost is written after the sweep)
         // LDS-only barrier: __syncthreads() would also wait for vmcnt(0), i.e. for this step's
         // store and for the lp prefetch of four steps ahead
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -175,6 +178,10 @@ __device__ __forceinline__ void lattice_sweep(
         fetch(k + 6, lb2, le2);
         step(k + 3, lb3, le3);
         fetch(k + 7, lb3, le3);
+    }
+    if (DIR == 1) {
+        const int any_bad = __syncthreads_or(bad ? 1 : 0);
+        if (u == 0) costs[b] = any_bad ? __builtin_nanf("") : (float)(-last);
     }
 }
 
@@ -260,11 +267,17 @@ __device__ __forceinline__ void lattice_chain(
         }
     };
 
+    // A NaN log-prob INSIDE the lattice (non-finite enc / pred / W / bias: a diverged run) must come out as a NaN cost, as it does from the
+    // reference's loss — but the clamp below canonicalises NaNs away (it has to: slots outside the lattice hold anything).  The beta sweep
+    // reads lp_blank of every lattice cell exactly once, and a cell whose logits hold a NaN has a NaN lp_blank (its denominator is NaN): one
+    // unordered compare per step under the validity mask, off the dependent chain, joined once at the end of the sweep.
+    bool bad = false;
     // ---- step 0: alpha[0,0] = 0; beta[Tb-1,Ub] = lp_blank there
     double prev;
     {
         const int d = DIR == 0 ? 0 : nd - 1;
         const double first = DIR == 0 ? 0.0 : (double)lpb[(long)d * U1 + Ub];
+        if (DIR == 1) bad = (u == Ub) && (first != first);
         prev = (u == (DIR == 0 ? 0 : Ub)) ? first : NINF;
         if (st_ok) out[(long)d * U1 + u] = prev;
         publish(0, prev);
@@ -289,6 +302,7 @@ __device__ __forceinline__ void lattice_chain(
         // fminf, not a bare v_min_f32: in IEEE mode the instruction turns a SIGNALLING NaN into a
         // quiet NaN result, and slots of the lp arrays that no kernel wrote may hold any bit pattern
         // (found by tools/fuzz_lattice.py); fminf canonicalises first (v_max x,x) and then returns 0
+        const bool lb_nan = lb != lb;  // (DIR == 1: lp_blank of THIS step's cell; used under `valid` below)
         lb = fminf(lb, 0.f);
         le = fminf(le, 0.f);
         const double a = prev + (double)lb;
@@ -300,6 +314,7 @@ __device__ __forceinline__ void lattice_chain(
         const double v = fmax(a, e) +
             (double)(__builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(dl * RNNT_LOG2E)) * 0.6931471805599453f);
         const bool valid = (unsigned)(d - ukey) < (unsigned)Tb;
+        if (DIR == 1) bad = bad || (valid && lb_nan);
         prev = valid ? v : NINF;
         publish(k, prev);
         if (st_ok) out[(long)d * U1 + u] = prev;
@@ -323,7 +338,10 @@ __device__ __forceinline__ void lattice_chain(
         fetch(k0, lb, le);
         step(k0, lb, le);
     }
-    if (DIR == 1 && u == 0) costs[b] = (float)(-prev);  // -beta[0,0]
+    if (DIR == 1) {  // (block-uniform branch: every wave of the beta sweep reaches this barrier — all spins are bounded)
+        const int any_bad = __syncthreads_or(bad ? 1 : 0);
+        if (u == 0) costs[b] = any_bad ? __builtin_nanf("") : (float)(-prev);  // -beta[0,0]
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_lattice_chain(

@@ -232,7 +232,7 @@ int rnnt_engine_conv_predictor_saved_bytes(int B, int U1, int S, int E, int O, s
 
 int rnnt_engine_conv_predictor_fwd(const int64_t *ids, int B, int U1, int S, int E, int O,
                                    const rnnt_conv_predictor_params *p, const uint8_t *keep1,
-                                   const uint8_t *keep2, float dropout_p, float ln_eps, float *out,
+                                   const uint8_t *keep2, float dropout_p, float ln_in_eps, float ln_out_eps, float *out,
                                    void *saved, size_t saved_bytes, void *stream)
 {
     if (int rc = check_pred_dims(B, U1, S, E, O)) return rc;
@@ -253,7 +253,7 @@ int rnnt_engine_conv_predictor_fwd(const int64_t *ids, int B, int U1, int S, int
     launch_pack_conv_w(p->conv2_w, ws + L.wp2, E, E, 5, st);
     // x1 = LN(embedding[ids])                                   predictor.py:214-215
     hipLaunchKernelGGL(k_ln_fwd<true>, dim3((M + 3) / 4), dim3(256), 0, st, p->embedding, ids, S, p->ln_in_w,
-                       p->ln_in_b, ln_eps, M, E, ws + L.x1, ws + L.st1);
+                       p->ln_in_b, ln_in_eps, M, E, ws + L.x1, ws + L.st1);
     // g1 = dropout(gelu(conv1(x1)))                              predictor.py:217-220
     SgArgs c1 = sg(ws + L.x1, E, ws + L.wp1, E, ws + L.g1, E, M, E, E, 3, U1);
     c1.bias = p->conv1_b; c1.Cpre = ws + L.y1; c1.act = 1; c1.mask = keep1; c1.mask_scale = scale;
@@ -267,7 +267,7 @@ int rnnt_engine_conv_predictor_fwd(const int64_t *ids, int B, int U1, int S, int
     l.bias = p->linear_b;
     launch_sgemm_nt(l, st);
     hipLaunchKernelGGL(k_ln_fwd<false>, dim3((M + 3) / 4), dim3(256), 0, st, ws + L.z, nullptr, 0, p->ln_out_w,
-                       p->ln_out_b, ln_eps, M, O, out, ws + L.st2);
+                       p->ln_out_b, ln_out_eps, M, O, out, ws + L.st2);
     return status("rnnt_engine_conv_predictor_fwd");
 }
 

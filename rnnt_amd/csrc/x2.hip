@@ -104,26 +104,36 @@ template <int N> struct X2Int { static constexpr int value = N; };
 #define X2_FLAG_LINEAR 0x40000000  // X3Args::flags: launch_joint_fwd_x2 runs the plain-GEMM form (k_joint_fwd_x2<2>: the joint's input projections)
 
 // ---------------------------------------------------------------------------------------
-// s_W = 2^(14 - ceil(log2 max|W|)) (1 for an all-zero or non-finite W): one workgroup, V*H/4 float4 reads.
+// s_W = 2^(14 - ceil(log2 max|W|)) (1 for an all-zero W): one workgroup, V*H/4 float4 reads.  A W with a NaN or an infinity in it (a diverged
+// run) keeps s_W = 1 and gets a NaN as 1 / s_W: the packs' clamp (v_med3) would otherwise turn the entry into a finite fp16 and the loss would stay
+// finite, where every other route — and the reference — report NaN.  Every logit and every dHidden entry is multiplied by 1 / s_W.
 // ---------------------------------------------------------------------------------------
+#define X2_F32_MAX 3.4028234663852886e38f
 __global__ __launch_bounds__(1024) void k_x2_wscale(const float *__restrict__ W, long n4, float *__restrict__ scales)
 {
     __shared__ float s_m[16];
     float m = 0.f;
+    bool bad = false;
     long i = threadIdx.x;
     for (; i + 7 * 1024 < n4; i += 8 * 1024) {  // eight loads in flight per thread (one at a time: a round trip per 16 KiB, 58 us for 2 MB)
         f32x4 w[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) w[k] = ((const f32x4 *)W)[i + 1024 * k];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(w[k][0]), fabsf(w[k][1]))), fmaxf(fabsf(w[k][2]), fabsf(w[k][3])));
+        for (int k = 0; k < 8; ++k) {
+            const float mw = fmaxf(fmaxf(fabsf(w[k][0]), fabsf(w[k][1])), fmaxf(fabsf(w[k][2]), fabsf(w[k][3])));
+            bad |= (w[k][0] != w[k][0]) | (w[k][1] != w[k][1]) | (w[k][2] != w[k][2]) | (w[k][3] != w[k][3]);  // (infinities show in the maximum)
+            m = fmaxf(m, mw);
+        }
     }
     for (; i < n4; i += 1024) {
         const f32x4 w = ((const f32x4 *)W)[i];
+        bad |= (w[0] != w[0]) | (w[1] != w[1]) | (w[2] != w[2]) | (w[3] != w[3]);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_x2_wscale(const float *__restrict__ W,
             s = __uint_as_float((unsigned)(127 + k) << 23);
         }
         scales[0] = s;
-        scales[1] = 1.0f / s;
+        scales[1] = (any_bad || e == 255) ? __uint_as_float(0x7fc00000u) : 1.0f / s;
     }
 }
 
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256) void k_x2_make_hidden(X3Args a)
     f32x4 t0 = fast_tanh_sum4(*(const f32x4 *)ep, *(const f32x4 *)pp);
     f32x4 t1 = fast_tanh_sum4(*(const f32x4 *)(ep + 4), *(const f32x4 *)(pp + 4));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { t0[k] = x2_clamp(t0[k] * X2_SH); t1[k] = x2_clamp(t1[k] * X2_SH); }  // (NaN operands stay NaN, as on every route)
+    for (int k = 0; k < 4; ++k) { t0[k] = x2_clamp(t0[k] * X2_SH); t1[k] = x2_clamp(t1[k] * X2_SH); }  // (hidden = tanh(.) is finite or NaN; v_med3 maps a NaN to -65504: non-finite enc / pred are caught upstream by k_x2_make_ep's flag and run the exact form)
     u32x4 ph, pm;
     X2_SPLIT4(t0, ph, pm, 0);
     X2_SPLIT4(t1, ph, pm, 2);
@@ -1859,19 +1869,25 @@ __global__ __launch_bounds__(256) void k_x2_absmax(X2AbsArgs a, float *__restric
     const long ld = a.ld[t], n = a.rows[t] * a.cols4[t];
     const int cols4 = a.cols4[t];
     float m = 0.f;
+    bool bad = false;  // a NaN or an infinity among the entries (fmaxf drops NaNs; the split's clamp would turn either into a finite fp16)
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
         const long r = idx / cols4;
         const int c = (int)(idx - r * cols4);
         const f32x4 w = *(const f32x4 *)(x + r * ld + 4 * c);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));  // (NaNs are dropped by fmaxf)
+        const float mw = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
+        bad = bad || !(fabsf(w[0]) <= X2_F32_MAX) || !(fabsf(w[1]) <= X2_F32_MAX) || !(fabsf(w[2]) <= X2_F32_MAX) || !(fabsf(w[3]) <= X2_F32_MAX);
+        m = fmaxf(m, mw);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) partial[t * 256 + blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    // a non-finite operand leaves a NaN as its workgroup's "maximum": k_x2_lin_scales turns it into a NaN reciprocal scale, and every output
+    // the operand feeds is multiplied by that — non-finite inputs give non-finite outputs, as torch.nn.functional.linear's do (round-5 advice)
+    if (threadIdx.x == 0) partial[t * 256 + blockIdx.x] = any_bad ? __uint_as_float(0x7fc00000u) : fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
-// one workgroup of 256: scales[2i] = 2^(14 - ceil(log2 max_i)), scales[2i + 1] = its reciprocal (1 for an all-zero or non-finite operand),
+// one workgroup of 256: scales[2i] = 2^(14 - ceil(log2 max_i)), scales[2i + 1] = its reciprocal (1 for an all-zero operand; NaN for an operand with a NaN or an infinity in it),
 // i = 0 .. n-1, from the partial maxima; the call's counter words zeroed (the forward's tile counter; dW's progress words) and dW's table written
 // (k_dw_table's format, B = 1, every granule live) — what four more launches did before
 __global__ __launch_bounds__(256) void k_x2_lin_scales(const float *__restrict__ partial, float *__restrict__ scales, int n, unsigned *__restrict__ zero0,
@@ -1880,12 +1896,16 @@ __global__ __launch_bounds__(256) void k_x2_lin_scales(const float *__restrict__
     __shared__ float s_m[4];
     for (int i = 0; i < n; ++i) {
         float m = partial[i * 256 + threadIdx.x];
+        const int nonfinite = __syncthreads_or(m != m ? 1 : 0);  // (k_x2_absmax: NaN = the operand holds a NaN or an infinity)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         __syncthreads();
         if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && nonfinite) {  // the planes / packs are finite garbage (scale 1, clamped); the outputs' unscale factor is NaN
+            scales[2 * i] = 1.0f;
+            scales[2 * i + 1] = __uint_as_float(0x7fc00000u);
+        } else if (threadIdx.x == 0) {
             const unsigned bits = __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
             float s = 1.0f;
             const int e = (int)(bits >> 23) & 0xff;

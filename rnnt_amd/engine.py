@@ -78,7 +78,7 @@ SIGNATURES = {
     "rnnt_engine_adamw_step": "ipppppdddddqpfip",
     "rnnt_engine_adamw_step_dev": "ippppppddddpppfip",
     "rnnt_engine_conv_predictor_saved_bytes": "iiiiip",
-    "rnnt_engine_conv_predictor_fwd": "piiiiipppffppzp",
+    "rnnt_engine_conv_predictor_fwd": "piiiiipppfffppzp",
     "rnnt_engine_conv_predictor_bwd": "piiiiipppfpppzp",
     "rnnt_engine_linear_fwd": "pqppiiipp",
     "rnnt_engine_linear_bwd_workspace_bytes": "iiip",
@@ -131,13 +131,15 @@ VARIANT_FWD_LDS_RING = 128
 VARIANT_FWD_ONE_WG_PER_TILE = 256
 VARIANT_X3_FP32_FWD = 4096  # bf16x3 route: this stage on the fp32 route's kernel (isolation checks; not bit-identical)
 VARIANT_X3_FP32_DH = 8192
-VARIANT_X3_FWD_2WG = 16384  # bf16x3 forward as two 4-wave workgroups per CU (k_joint_fwd_x3d<4>; measured slower than the default)
-VARIANT_X3_FWD_8W = 65536   # ... as one 8-wave workgroup per CU (k_joint_fwd_x3d<8>)
-VARIANT_X3_FWD_Z = 262144   # bf16x3 forward as k_joint_fwd_x3z (one wave per SIMD, two M tiles per wave, 256 x 256 tiles)
-VARIANT_X2_FWD_2WG = 1048576  # f16x2 forward as two 4-wave workgroups per CU (k_joint_fwd_x2d)
-VARIANT_X2_DW_P16 = 2097152  # f16x2 dW on v_mfma_f32_16x16x32_f16 (k_dw_x2p)
-VARIANT_X2_DW_8W = 524288   # f16x2 dW as 8 waves per workgroup (two per SIMD, k_dw_x2<8>) instead of the default 4 (measured equal)
-VARIANT_X3_DW_P16 = 131072  # bf16x3 dW on v_mfma_f32_16x16x32_bf16, two products per MFMA (k_dw_x3p) instead of the default k_dw_x3
+# kernels of the diagnostic library only (rnnt_amd/csrc/lab/rnnt_engine_lab.h; tools/build_lab.sh): librnnt_engine.so refuses these bits
+VARIANT_LAB_MASK = 0x7FFFC000
+VARIANT_X3_FWD_2WG = 16384
+VARIANT_X3_FWD_8W = 65536
+VARIANT_X3_FWD_Z = 262144
+VARIANT_X2_FWD_2WG = 1048576
+VARIANT_X2_DW_P16 = 2097152
+VARIANT_X2_DW_8W = 524288
+VARIANT_X3_DW_P16 = 131072
 STAGES_ALL = 255
 STAGES_FORWARD = 7  # operand producers + joint-forward GEMM + lattice sweep: costs only
 
@@ -649,8 +651,16 @@ def greedy_decode_persistent(frames, pred_params, ln_eps, text_W, text_b, W, bia
     return state, tokens
 
 
+DECODE_RANGE_CODES = (10, 11)  # decode.hip DP_CODE_FRAME_RANGE / DP_CODE_TEXT_RANGE
+
+
 def check_decode_state(state_list):
-    """After the synchronisation: raise if the persistent loop gave up (state[7]: the hand-off that never arrived)."""
+    """After the synchronisation: raise if the persistent loop did not decode — state[7]: the hand-off that never arrived, or 10 / 11: an
+    audio frame / a text vector with an entry beyond +-30 (or non-finite), where tanh(e + p) = 1 - 2 / (1 + exp 2e exp 2p) is not exact
+    (greedy_decode_loop takes tanh of the sum and has no such limit)."""
+    if state_list[7] in DECODE_RANGE_CODES:
+        raise RuntimeError(f"rnnt_engine: the persistent greedy decode met an {'audio frame' if state_list[7] == 10 else 'text vector'} "
+                           "entry beyond +-30 (or non-finite): use greedy_decode_loop for this utterance")
     if state_list[7] != 0:
         raise RuntimeError(f"rnnt_engine: the persistent greedy decode gave up waiting for hand-off {state_list[7]} "
                            f"(iteration {state_list[5]}, {state_list[6]} workgroups): are all of its workgroups resident?")

@@ -123,10 +123,13 @@ class RNNTModel(torch.nn.Module):
             host = both.tolist() if both is not None else None  # the utterance's one synchronisation
             st = host[:8] if host is not None else state.tolist()
             if persistent and st[7] != 0:
-                # the persistent loop gave up waiting for a hand-off (its workgroups were not all resident: a device shared with another
-                # process or stream's long kernels): nothing it wrote is a decode — run the kernel-per-layer loop, which needs no residency
-                warnings.warn(f"rnnt_amd: the persistent greedy decode gave up at hand-off {st[7]} (iteration {st[5]}); "
-                              "falling back to the kernel-per-layer loop", RuntimeWarning)
+                # st[7] < 10: the persistent loop gave up waiting for a hand-off (its workgroups were not all resident: a device shared
+                # with another process or stream's long kernels).  st[7] >= 10 (engine.DECODE_RANGE_CODES): an audio frame or a text
+                # vector beyond +-30, where the loop's factored tanh is not exact.  Either way nothing it wrote is a decode — run the
+                # kernel-per-layer loop, which needs no residency and takes tanh of the sum
+                if st[7] not in engine.DECODE_RANGE_CODES:
+                    warnings.warn(f"rnnt_amd: the persistent greedy decode gave up at hand-off {st[7]} (iteration {st[5]}); "
+                                  "falling back to the kernel-per-layer loop", RuntimeWarning)
                 state, toks = engine.greedy_decode_loop(*args, max_per_frame=10,
                                                         scan_frames=max(1, min(int(scan_frames) if scan_frames > 0 else 64, 128)))
                 st, host = state.tolist(), None
@@ -230,7 +233,7 @@ class RNNTModel(torch.nn.Module):
         out = []
         for (state, mel), l in zip(pending, lens):
             host = state._with_tokens.tolist()
-            if host[7] != 0:  # this decode gave up waiting for a hand-off (see greedy_decode): once more, alone
+            if host[7] != 0:  # this decode gave up waiting for a hand-off, or met an activation beyond +-30 (see greedy_decode): once more, alone
                 out.append(self.greedy_decode(mel, l, max_length=max_length))
             else:
                 out.append(host[9:9 + host[2]])

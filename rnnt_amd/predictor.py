@@ -45,7 +45,7 @@ def _struct(tensors):
 
 class _ConvPredictorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, keep1, keep2, p, eps, *params):
+    def forward(ctx, ids, keep1, keep2, p, eps_in, eps_out, *params):
         dev = engine._require_cuda(ids, *params)
         engine._require_dtype(torch.float32, **{f"param{i}": t for i, t in enumerate(params)})
         engine._require_dtype(torch.int64, ids=ids)
@@ -63,7 +63,7 @@ class _ConvPredictorFn(torch.autograd.Function):
             st = _struct(params)
             engine._check(lib.rnnt_engine_conv_predictor_fwd(
                 engine._p(ids), B, U1, S, E, O, ctypes.byref(st), engine._p(keep1), engine._p(keep2),
-                ctypes.c_float(p), ctypes.c_float(eps), engine._p(out), engine._p(saved),
+                ctypes.c_float(p), ctypes.c_float(eps_in), ctypes.c_float(eps_out), engine._p(out), engine._p(saved),
                 ctypes.c_size_t(saved.numel()), engine._stream(dev)))
         ctx.save_for_backward(ids, keep1, keep2, saved, *params)
         ctx.p = p
@@ -85,7 +85,7 @@ class _ConvPredictorFn(torch.autograd.Function):
                 engine._p(ids), B, U1, S, E, O, ctypes.byref(sp), engine._p(keep1), engine._p(keep2),
                 ctypes.c_float(ctx.p), engine._p(grad_out), ctypes.byref(sg), engine._p(saved),
                 ctypes.c_size_t(saved.numel()), engine._stream(dev)))
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class ConvPredictor(torch.nn.Module):
@@ -115,4 +115,4 @@ class ConvPredictor(torch.nn.Module):
             shape = (*input.shape, self.embedding.embedding_dim)
             keep1 = (torch.rand(shape, device=input.device) >= p).to(torch.uint8)
             keep2 = (torch.rand(shape, device=input.device) >= p).to(torch.uint8)
-        return _ConvPredictorFn.apply(input, keep1, keep2, p, float(self.output_layer_norm.eps), *self._params())
+        return _ConvPredictorFn.apply(input, keep1, keep2, p, float(self.input_layer_norm.eps), float(self.output_layer_norm.eps), *self._params())

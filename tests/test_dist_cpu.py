@@ -2,7 +2,6 @@
 joint+loss gradients (the CPU oracle stands in for the engine call — no GPU here), and ONE
 all-reduce of the flat [dW | db | loss] buffer must reproduce the full-batch result."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -13,18 +12,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _rdzv(tmp_path):
+    """file:// rendezvous inside the test's own temporary directory (one node): no TCP port to pick, so no bind / close / reuse window."""
+    return f"file://{tmp_path}/rdzv"
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, rdzv, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     from oracle import cpu_oracle
     from rnnt_amd.parallel import FlatGrad, shard_bounds
     from tests.helpers import make_inputs
@@ -47,7 +42,7 @@ def _worker(rank, world, port, out):
 
 def test_two_rank_allreduce_matches_full_batch(tmp_path):
     out = str(tmp_path / "r0.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _rdzv(tmp_path), out), nprocs=2, join=True)
     z = np.load(out)
     from oracle import cpu_oracle
     from tests.helpers import make_inputs
@@ -72,10 +67,9 @@ def test_shard_bounds_cover_batch():
 
 
 # ---- BucketGradNorm's communication hook and RcclComm's id hand-round with two real ranks (gloo)
-def _hook_worker(rank, world, port, out):
+def _hook_worker(rank, world, rdzv, out):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=rdzv, rank=rank, world_size=world)
     from rnnt_amd.optim import BucketGradNorm
     from rnnt_amd.parallel import RcclComm
     torch.manual_seed(0)  # identical replicas
@@ -124,7 +118,7 @@ def test_bucket_grad_norm_hook_and_unique_id_exchange_two_ranks(tmp_path):
     clip_grad_norm_ computes on a twin under DDP's default hook (gradients bit-identical), over several
     iterations and several buckets per backward; RcclComm.share_unique_id hands rank 0's 128 bytes round intact."""
     out = str(tmp_path / "hook.npz")
-    mp.spawn(_hook_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_hook_worker, args=(2, _rdzv(tmp_path), out), nprocs=2, join=True)
     z = np.load(out)
     assert (z["nbuckets"][1:] >= 2).all(), z["nbuckets"]  # (DDP lays its buckets out for good after the first backward)
     for got, want in z["totals"]:

@@ -152,22 +152,36 @@ def test_projected_joint_single_forward_stays_plain_torch_on_cpu(golden_dir):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/rnnt"), reason="needs the reference checkout (build container only)")
-def test_overlay_package_swaps_joint_and_model_only():
-    """integration/rnnt placed before the reference on PYTHONPATH: `rnnt.joint.JointNetwork` (the hydra
-    target, train.py:63) and `rnnt.model.RNNTModel` (train.py:19) become the engine's classes — rnnt.model
-    imports without torchaudio — while rnnt.predictor / rnnt.jasper / rnnt.lr_sched still come from the
-    reference's own files."""
+def test_overlay_package_swaps_joint_model_and_conv_predictor_only():
+    """integration/rnnt placed before the reference on PYTHONPATH: `rnnt.joint.JointNetwork` (the hydra target, train.py:63),
+    `rnnt.model.RNNTModel` (train.py:19) and `rnnt.predictor.ConvPredictor` (the hydra target of config/basic_sp_convjs*.yaml:20-25,
+    train.py:61) become the engine's classes — rnnt.model imports without torchaudio — while rnnt.predictor.LSTMPredictor IS the
+    reference's class and rnnt.jasper / rnnt.lr_sched / rnnt.causalconv still come from the reference's own files.  With the engine's
+    ConvPredictor in place the model's evaluation decode is eligible for the device loop (the rest of `_device_loop_ok` needs a GPU)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
-        "import rnnt, rnnt.joint, rnnt.model, rnnt.predictor, rnnt.jasper, rnnt.lr_sched, rnnt_amd\n"
+        "import rnnt, rnnt.joint, rnnt.model, rnnt.predictor, rnnt.jasper, rnnt.lr_sched, rnnt.causalconv, rnnt_amd\n"
         "assert rnnt.joint.JointNetwork is rnnt_amd.JointNetwork\n"
         "assert rnnt.model.RNNTModel is rnnt_amd.RNNTModel\n"
-        "assert rnnt.predictor.__file__.startswith('/root/reference/'), rnnt.predictor.__file__\n"
-        "assert rnnt.jasper.__file__.startswith('/root/reference/')\n"
-        "m = rnnt.model.RNNTModel(rnnt.predictor.ConvPredictor(16, 32, 8, 0.1), rnnt.jasper.AudioEncoder if False else None, rnnt.joint.JointNetwork(-1, -1, 32, 16))\n"
+        "assert rnnt.predictor.ConvPredictor is rnnt_amd.ConvPredictor\n"
+        "assert rnnt.predictor.LSTMPredictor.__module__ == 'rnnt._reference_predictor'\n"
+        "assert rnnt.predictor.ReferenceConvPredictor is not rnnt_amd.ConvPredictor\n"
+        "import inspect; assert inspect.getsourcefile(rnnt.predictor.LSTMPredictor).startswith('/root/reference/')\n"
+        "assert rnnt.jasper.__file__.startswith('/root/reference/') and rnnt.causalconv.__file__.startswith('/root/reference/')\n"
+        "from rnnt.predictor import LSTMPredictor, ConvPredictor\n"  # (the reference's own import line, rnnt/model.py:3)
+        "m = rnnt.model.RNNTModel(rnnt.predictor.ConvPredictor(16, 32, 8, 0.1), None, rnnt.joint.JointNetwork(-1, -1, 32, 16))\n"
         "assert sorted(k for k in m.state_dict() if k.startswith('joint.')) == ['joint.joint_ln.bias', 'joint.joint_ln.weight']\n"
+        "ref = rnnt.predictor.ReferenceConvPredictor(16, 32, 8, 0.1)\n"
+        "assert list(ref.state_dict()) == list(m.predictor.state_dict())\n"  # checkpoints move both ways
+        "lstm = rnnt.predictor.LSTMPredictor(16, 32, 8, 1, 16, 0.1, 0.1)\n"
+        "assert rnnt.model.RNNTModel(lstm, None, rnnt.joint.JointNetwork(-1, -1, 32, 16))._predictor_is_stateful()\n"
+        "try:\n"
+        "    rnnt.predictor.no_such_name\n"
+        "    raise SystemExit('missing attribute did not raise')\n"
+        "except AttributeError:\n"
+        "    pass\n"
         "print('overlay ok')\n")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "integration"), root, "/root/reference"]))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

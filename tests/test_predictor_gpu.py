@@ -124,6 +124,42 @@ def test_engine_linear_x2_fwd_bwd_vs_float64(M, K, N, xscale, gscale):
     assert torch.equal(y2, y.detach())
 
 
+@pytest.mark.parametrize("where", ["x", "W", "dy"])
+@pytest.mark.parametrize("what", [float("nan"), float("inf"), float("-inf")])
+def test_engine_linear_x2_propagates_non_finite_operands(where, what):
+    """A NaN or an infinity in x, W or dy must not come out finite (round-5 advice: the operand split clamps into fp16's range, the
+    magnitude search drops NaNs — a diverged run would keep training on garbage).  Wherever torch.nn.functional.linear and its
+    autograd give a non-finite entry, rnnt_engine_linear_x2_fwd / _bwd do too (they may poison more: the whole result the operand feeds);
+    results the operand does not feed stay exactly what they are without it."""
+    import rnnt_amd
+    torch.manual_seed(3)
+    M, K, N = 200, 256, 128
+    x = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    G = torch.randn(M, N, device="cuda")
+
+    def run(x_, W_, G_, fn):
+        xr, Wr, br = (t.clone().requires_grad_(True) for t in (x_, W_, b))
+        y = fn(xr, Wr, br)
+        y.backward(G_)
+        return y.detach(), xr.grad, Wr.grad, br.grad
+
+    clean = run(x, W, G, lambda a_, w_, b_: rnnt_amd.linear(a_, w_, b_, backend="x2"))
+    xs, Ws, Gs = x.clone(), W.clone(), G.clone()
+    {"x": xs, "W": Ws, "dy": Gs}[where][7, 33] = what
+    got = run(xs, Ws, Gs, lambda a_, w_, b_: rnnt_amd.linear(a_, w_, b_, backend="x2"))
+    ref = run(xs, Ws, Gs, torch.nn.functional.linear)
+    for name, g, r, c in zip(("y", "dx", "dW", "db"), got, ref, clean):
+        bad_ref = ~torch.isfinite(r)
+        assert not torch.isfinite(g[bad_ref]).any(), (name, where, what)
+        if not bad_ref.any():  # the operand does not reach this result: untouched
+            assert torch.equal(g, c), (name, where, what)
+    fed = {"x": ("y", "dW"), "W": ("y", "dx"), "dy": ("dx", "dW", "db")}[where]
+    for name, r in zip(("y", "dx", "dW", "db"), ref):
+        assert (name in fed) == bool((~torch.isfinite(r)).any()), (name, where)  # (the test's own premise about what feeds what)
+
+
 def test_joint_projections_default_to_the_engine_from_a_work_threshold():
     """JointNetwork.projection_backend = "auto": audio_ln (B*T rows) on the engine's f16x2 kernels from engine.LINEAR_X2_MIN_MKN of work
     (rows x in x out), text_ln (B*U1 rows, below it here) through the library; both within the fp32 bar of float64 torch, gradients included."""
