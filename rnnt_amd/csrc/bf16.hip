@@ -30,6 +30,22 @@
 // fragments are consumed, so staging a chunk is a linear copy L2 -> VGPR -> LDS.
 #include "kernels.hpp"
 
+// Diagnostic build only (-DBF_CLOCK, with an engine.o built -DRNNT_STAMPS so that Bf16Args::debug is set; tools/bf16_whatif.sh): workgroup
+// (0,0,0) stamps the core clock counter and the 100 MHz reference at its start and end into debug[SLOT .. SLOT+3] (a buffer nothing
+// else reads): the clock the launch ran at = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/exp_bf16_clock.py).
+#ifdef BF_CLOCK
+#define BF_CLOCK_STAMP(SLOT)                                                                                               \
+    do {                                                                                                                   \
+        if (a.debug && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {                        \
+            unsigned long long t_, r_;                                                                                     \
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");      \
+            a.debug[SLOT] = t_; a.debug[(SLOT) + 1] = r_;                                                                  \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define BF_CLOCK_STAMP(SLOT) do {} while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -496,6 +512,7 @@ __global__ __launch_bounds__(256, (KC <= 8 ? 2 : 1)) void k_joint_fwd_bf16_ra(Bf
     const long cells = (long)a.B * T * U1, per = (long)T * U1;
     const long c_first = (long)blockIdx.x * 128;
     if (c_first >= cells) return;
+    BF_CLOCK_STAMP(300);
     // a tile entirely in the dead time steps (t >= T_b) of one utterance: hidden only (finite rows for k_dw_bf16);
     // its logits are never read (k_dhidden_bf16 zero-fills the G rows of dead tiles itself)
     bool dead;
@@ -767,6 +784,7 @@ __global__ __launch_bounds__(256, (KC <= 8 ? 2 : 1)) void k_joint_fwd_bf16_ra(Bf
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed(g0, true);
     FRSTAMP(60);
+    BF_CLOCK_STAMP(302);
 
     // ---- log-softmax denominator of cell j: the two column halves (lanes j and j+32), then the two log-probs
     float den;
@@ -928,6 +946,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
 
+    if (FIRST) BF_CLOCK_STAMP(304);
     auto produce = [&](const u32x4 &x, int c, int slot) {
         if constexpr (!FIRST) { s_g[slot * 512 + gdst] = x; return; }
         if (DH_OFF(2)) { s_g[slot * 512 + gdst] = x; return; }
@@ -1038,6 +1057,7 @@ __global__ __launch_bounds__(512, 1) void k_dhidden_bf16(Bf16Args a, const int h
         }
     }
 
+    if (FIRST) BF_CLOCK_STAMP(306);
     // ---- epilogue.  Accumulator register r of tile 4mt+q (mt = 0,1): row (r&3) + 8(r>>2) + 4*half
     // of M-tile 2wm+mt = (t-row 2(2wm+mt) + (r>>3), u (r&3) + 8((r>>2)&1) + 4*half), column 128wn + 4j + q.
     if (RNNT_XP(a.flags, 8192) || DH_OFF(32)) {  // (the accumulators stay "used": without this the MFMAs are dead code too)
@@ -1152,6 +1172,13 @@ void launch_dhidden_bf16(const Bf16Args &a, hipStream_t st)
 // ---------------------------------------------------------------------------------------
 #define BW_ROWS 32   // cells per stage (2 MFMA k-steps)
 #define BW_NST 4     // ring stages
+// Diagnostic builds only (-DBW_EXP=bits, VAR=BW_EXP tools/build_bf16_variants.sh): parts of k_dw_bf16 compiled out (results wrong by
+// construction) — 1 no MFMAs, 2 no db (v_dot2c), 4 no transposed fragment reads, 8 no DMA bytes (requested past the buffer's range: the
+// instruction and its vmcnt stay), 16 no DMA instructions, 32 no barrier, 64 no lockstep with the split's other tiles
+#ifndef BW_EXP
+#define BW_EXP 0
+#endif
+#define BW_OFF(bit) ((BW_EXP) & (bit))
 
 __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 {
@@ -1176,6 +1203,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
     const int B = a.B;
     const long nlive = tab[2 * B + 1];
     const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+    BF_CLOCK_STAMP(308);
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -1203,7 +1231,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         int soff[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            soff[i] = (int)((4 * i + (lane >> 4)) * rstride) + 16 * ((lane & 15) ^ (((lane >> 4) << 2) | (i & 3))) - 1024 * (i & 3);
+            soff[i] = BW_OFF(8) ? 0x7ffffff0 : (int)((4 * i + (lane >> 4)) * rstride) + 16 * ((lane & 15) ^ (((lane >> 4) << 2) | (i & 3))) - 1024 * (i & 3);
         // (round 5: pieces 4g .. 4g+3 share one LDS base (M0) and carry the immediate offset 1024 (i & 3), which advances the memory address
         // too — taken back out of the per-lane offset above: rstride >= 256 bytes, so 4 i rows >= 1024 (i & 3) bytes)
         // (raw-buffer form: the 32 rows of a stage as a buffer with a wave-uniform base — scalar arithmetic only; the
@@ -1213,6 +1241,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             return __builtin_amdgcn_make_buffer_rsrc((void *)(src + st * (BW_ROWS * rstride)), 0, (int)(BW_ROWS * rstride), 0x00020000);
         };
         auto dma_stage = [&](long st, int slot) {
+            if (BW_OFF(16)) return;
             const __amdgpu_buffer_rsrc_t r = stage_rsrc(st);
             char *dst = s_ring + slot * 32768 + wave * 8192;
 #pragma unroll
@@ -1252,7 +1281,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         };
         struct Frags { u32x2 al[4], ah[4], bl[4], bh[4]; };
         auto reads = [&](Frags &f, int slot, int ks) {  // 16 transposed reads, NOT waited for
-            if (RNNT_XP(a.flags, 4096)) return;  // experiment switch
+            if (RNNT_XP(a.flags, 4096) || BW_OFF(4)) return;  // experiment switch
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int a0 = a_tile + slot * 32768 + 4096 * ks, b0 = b_tile + slot * 32768 + 4096 * ks;
@@ -1285,14 +1314,14 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             }
 #pragma unroll
             for (int qm = 0; qm < 4; ++qm) {
-                if (!RNNT_XP(a.flags, 1024)) {
+                if (!RNNT_XP(a.flags, 1024) && !BW_OFF(1)) {
 #pragma unroll
                     for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = mfma_bf16(fa[qm], fb[qn], acc[qm][qn]);
                 }
-                if (!RNNT_XP(a.flags, 8192)) dma_piece(dst, dslot, piece0 + qm);
+                if (!RNNT_XP(a.flags, 8192) && !BW_OFF(16)) dma_piece(dst, dslot, piece0 + qm);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (do_b && !RNNT_XP(a.flags, 2048)) {
+            if (do_b && !RNNT_XP(a.flags, 2048) && !BW_OFF(2)) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1313,7 +1342,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
         // looking, so every wave reaches the end whatever the others do.
         constexpr int DW_LAG = 3, DW_NAPS = 256;
         int *prog = a.dw_prog ? a.dw_prog + split * 16 : nullptr;
-        bool sync_on = prog != nullptr && tiles > 1 && tiles <= 16;
+        bool sync_on = prog != nullptr && tiles > 1 && tiles <= 16 && !BW_OFF(64);
         const int *nb = prog ? prog + (tile + 1 < tiles ? tile + 1 : 0) : nullptr;  // the neighbour's word
         int nb_at = 0x7fffffff;  // the neighbour's stage count as of the last look
         int done = 0;  // stages behind this workgroup, over all ranges
@@ -1357,6 +1386,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
             // stage st+1: younger in flight = stage st+2 (8 DMAs) + the 4 pieces just issued
             // (+ wave 0's progress store now and then: one more outstanding operation only makes the wait stricter)
             asm volatile(RNNT_VMCNT(12) ::: "memory");
+            if (BW_OFF(32)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
             lds_barrier();  // B_{st+1}; its lgkmcnt(0) also covers Y and the neighbour's progress word
             landed(Y, false);
             reads(X, (slot + 1) & 3, 0);  // past the last stage: reads a landed, unused slot
@@ -1372,6 +1402,7 @@ __global__ __launch_bounds__(256, 1) void k_dw_bf16(Bf16Args a)
 
     // ---- epilogue: partial slab [split][V,H]; bias partial [split][V].  Accumulator register r
     // of tile (qm,qn): v = v0 + 32qm + (r&3) + 8(r>>2) + 4half, h = h0 + 32qn + (lane&31).
+    BF_CLOCK_STAMP(310);
     const int v0 = vb * 256 + wm * 128, h0 = hb * 256 + wn * 128;
     float *sw = a.slab_w + (long)split * V * H;
 #pragma unroll

@@ -43,6 +43,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define X2_CLOCK_STAMP(SLOT) do {} while (0)
 #endif
 
+#ifndef X2_REREAD
+#define X2_REREAD 0  // 1: passes after a tile's first load the stored hidden planes back instead of producing them again — built, parity-green, measured SLOWER (cfg2 forward 21.23 vs 20.98 ms, same box: profiles/r06_fwd_whatif.txt): the planes are unique bytes per lane from L2, E and P are L1-resident rows
+#endif
 // compile-time experiment switches (-DX2_NT=bits): 1 non-temporal logits loads in k_dhidden_x2, 2 non-temporal operand DMAs in k_dw_x2<4>
 #ifndef X2_NT
 #define X2_NT 0
@@ -1451,7 +1454,14 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         // DMAs issued behind these loads a k-step ago.  Spelling the loads as asm with a counted wait was tried and is WRONG: the
         // loaded registers are loop-carried, and the copies hipcc places on the loop's back edge read them before the data has
         // landed — intermittently different results at full size, tools/dbg_x2_loss.py.)
-        auto op_load1 = [&](Opd &o, int kcs, int k) {  // one of the four 16-byte operand loads of k index kcs
+        // PL (round 6): the operand of k index kcs is the PAIR OF PLANES this lane stored for it in the tile's first pass (its own 2 x 16 bytes,
+        // hdst[2 kcs] and the same slot of the second plane): two loads instead of four, and nothing to compute — see run_pass.
+        auto op_load1 = [&](Opd &o, int kcs, int k, auto planes_c) {  // one of the four (PL: two) 16-byte operand loads of k index kcs
+            if (decltype(planes_c)::value) {
+                if (k == 0) o.e0 = __builtin_bit_cast(f32x4, hdst[2 * kcs]);
+                else if (k == 1) o.e1 = __builtin_bit_cast(f32x4, hdst[2 * kcs + ps]);
+                return;
+            }
             if (X2_EXP & 512) { const float c = (float)kcs * 0.01f; o.e0 = o.e1 = o.p0 = o.p1 = f32x4{c, -c, 0.5f * c, 0.25f}; return; }
             const float *e = ep + ek * kcs, *q = pp + pk * kcs;
             if (k == 0) o.e0 = *(const f32x4 *)e;
@@ -1462,12 +1472,14 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
         };
         auto op_load = [&](Opd &o, int kcs) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) op_load1(o, kcs, k);
+            for (int k = 0; k < 4; ++k) op_load1(o, kcs, k, X2Int<0>{});
         };
         // pieces 0-7: 2^14 tanh of the 4 pairs (fast_tanh2's arithmetic: exp2 half, reciprocal half); 8-15: the 2-way split
         // of each pair (hi + residuals, then mid); 16: the two ring writes
-        auto prod_piece = [&](Prod &P, const Opd &o, auto off_c, int k) {  // off_c: byte offset of the target A slot in the ring
-            if ((X2_EXP & 32) && k < 16) {
+        auto prod_piece = [&](Prod &P, const Opd &o, auto off_c, int k, auto planes_c) {  // off_c: byte offset of the target A slot in the ring
+            if (decltype(planes_c)::value && k < 16) {  // the operand IS the two planes: nothing to produce
+                if (k == 15) { P.ph = __builtin_bit_cast(u32x4, o.e0); P.pm = __builtin_bit_cast(u32x4, o.e1); }
+            } else if ((X2_EXP & 32) && k < 16) {
                 if (k == 0) { P.ph = __builtin_bit_cast(u32x4, o.e0 + o.e1); P.pm = __builtin_bit_cast(u32x4, o.p0 + o.p1); }
             } else if (k < 8) {
                 const int j = k >> 1;
@@ -1529,7 +1541,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                 Opd o; Prod P;
                 op_load(o, kc);
 #pragma unroll
-                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
+                for (int pc = 0; pc < 16; ++pc) prod_piece(P, o, X2Int<0>{}, pc, X2Int<0>{});
                 hid_store(P, kc);
             }
             tile = next;
@@ -1585,7 +1597,7 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             op_load(oset[1], KC > 1 ? 1 : 0);
             op_load(o, 0);
 #pragma unroll
-            for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, X2Int<0>{}, pc);
+            for (int pc = 0; pc < 17; ++pc) prod_piece(P, o, X2Int<0>{}, pc, X2Int<0>{});
             if (!LIN) hid_store(P, 0);  // (the plain GEMM stores nothing beside Y: X3Args::hidden is null there)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // W of k-steps 0-2 (this wave's share), operands, the stores
             x2_lds_barrier();                                 // ... of every wave; A slot 0 written
@@ -1610,8 +1622,11 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
           //   block 2  ah.bm  + the 12 fragment reads of k-step cs+1 (into the other register set) + the 8 DMAs of W(cs+3) into
           //            the slot W(cs) just left (three slots, filled THREE k-steps ahead) + (first pass) the 2 hidden stores
           // PAR = the k-step's parity = its A ring slot and fragment register set (KC is even: cs and kc have the same parity).
-          auto kstep = [&](auto par_c, const int kc) {
+          // OCP: the operands of k-step cs+1 (requested during the previous k-step) are its stored planes; ONP: this k-step requests the
+          // planes of k-step cs+2 (round 6, below)
+          auto kstep = [&](auto par_c, const int kc, auto ocp_c, auto onp_c) {
             constexpr int par = decltype(par_c)::value;
+            constexpr bool OCP = decltype(ocp_c)::value != 0, ONP = decltype(onp_c)::value != 0;
             constexpr int XN = (1 - par) * XF2_ASLOT;
             Frag &fc = fr[par], &fn = fr[1 - par];
             const int ws = wb + wsl * XF2_WSLOT;  // (the W slot is a run-time third: one v_add per k-step)
@@ -1634,12 +1649,12 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
                     }
                     if (BLK == 0) {
                         if (!(X2_EXP & 2048)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[q]) : "v"(ws), "n"(16384 + q * 1024));
-                        prod_piece(P, ocur, X2Int<XN>{}, q);
+                        prod_piece(P, ocur, X2Int<XN>{}, q, X2Int<OCP>{});
                     }
                     if (BLK == 1) {
-                        if (q < (LIN ? 2 : 4)) op_load1(onext, kcnn, q);  // operands of k-step cs+2 (needed a whole k-step from now): in FRONT of the k-step's DMAs
-                        if (q < 4) { prod_piece(P, ocur, X2Int<XN>{}, 8 + 2 * q); prod_piece(P, ocur, X2Int<XN>{}, 9 + 2 * q); }
-                        if (q == 4) prod_piece(P, ocur, X2Int<XN>{}, 16);  // the ring writes: done well before the barrier's lgkmcnt(0)
+                        if (q < ((LIN || ONP) ? 2 : 4)) op_load1(onext, kcnn, q, X2Int<ONP>{});  // operands of k-step cs+2 (needed a whole k-step from now): in FRONT of the k-step's DMAs
+                        if (q < 4) { prod_piece(P, ocur, X2Int<XN>{}, 8 + 2 * q, X2Int<OCP>{}); prod_piece(P, ocur, X2Int<XN>{}, 9 + 2 * q, X2Int<OCP>{}); }
+                        if (q == 4) prod_piece(P, ocur, X2Int<XN>{}, 16, X2Int<OCP>{});  // the ring writes: done well before the barrier's lgkmcnt(0)
                     }
                     if (BLK == 2) {  // nothing of the k-step is issued outside an MFMA's shadow: the 12 fragment reads of k-step cs+1, the 8 DMAs, the 2 stores
                         if (q < 4) { frag_read1(fn, X2Int<XN>{}, wsn, 2 * q); frag_read1(fn, X2Int<XN>{}, wsn, 2 * q + 1); }
@@ -1659,10 +1674,15 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             // them came (first pass) 2 hidden stores, k-step cs-1's 4 operand loads, 8 DMAs and (first pass) 2 stores, and this
             // k-step's 4 operand loads.  The first two k-steps of a pass: their W(cs+1) was waited for before the previous pass's
             // logits stores (pass end below) / with the tile prologue.
+            // (round 6: a k-step whose operands are stored planes issues 2 loads, not 4: previous k-step's loads = OCP ? 2 : 4, this one's
+            // = ONP ? 2 : 4)
             if (kc >= 2) {
-                if (LIN) asm volatile(RNNT_VMCNT(12) ::: "memory");  // (2 operand loads per k-step: 2 + 8 + 2)
-                else if (STORE) asm volatile(RNNT_VMCNT(20) ::: "memory");
-                else asm volatile(RNNT_VMCNT(16) ::: "memory");
+                constexpr int NV = LIN ? 12 : (STORE ? 4 : 0) + (OCP ? 2 : 4) + 8 + (ONP ? 2 : 4);
+                static_assert(NV == 12 || NV == 16 || NV == 18 || NV == 20, "counted vmcnt of the forward's k-step");
+                if (NV == 12) asm volatile(RNNT_VMCNT(12) ::: "memory");  // (LIN: 2 operand loads per k-step: 2 + 8 + 2; planes: the same)
+                else if (NV == 16) asm volatile(RNNT_VMCNT(16) ::: "memory");
+                else if (NV == 18) asm volatile(RNNT_VMCNT(18) ::: "memory");
+                else asm volatile(RNNT_VMCNT(20) ::: "memory");
             }
             X2STAMP(3);
             if (!(X2_EXP & 4096)) x2_lds_barrier();  // (lgkmcnt(0): bn and the ring writes) publishes A(cs+1), W(cs+1); frees W(cs)'s slot
@@ -1675,7 +1695,21 @@ __global__ __launch_bounds__(256, 1) void k_joint_fwd_x2(X3Args a, const int nti
             ++cs;
             wsl = wsn;
           };
-          for (int kc0 = 0; kc0 < KC; kc0 += 2) { kstep(X2Int<0>{}, kc0); kstep(X2Int<1>{}, kc0 + 1); }
+          // Round 6: only a tile's FIRST pass produces the hidden values.  It stores them as two fp16 planes for k_dw_x2 anyway, and every
+          // lane stores exactly the 2 x 16 bytes it later needs as its A-ring slot — so the passes after the first load those back (the
+          // lane's own stores, a whole pass old: landed; no other workgroup touches the rows) instead of loading E and P and running the
+          // fma / rcp / fma / split arithmetic again: 2 operand loads per k-step instead of 4 and no production VALU in V/512 - 1 of the
+          // V/512 passes (config 2: one of two; config 5: 31 of 32).  Operands are requested two k-steps ahead, so the first pass's last two
+          // k-steps already request planes (of the next pass's k-steps 0 and 1), and its last one copies where it used to produce.
+          if constexpr (LIN || !X2_REREAD) {
+              for (int kc0 = 0; kc0 < KC; kc0 += 2) { kstep(X2Int<0>{}, kc0, X2Int<0>{}, X2Int<0>{}); kstep(X2Int<1>{}, kc0 + 1, X2Int<0>{}, X2Int<0>{}); }
+          } else if constexpr (STORE) {
+              for (int kc0 = 0; kc0 < KC - 2; kc0 += 2) { kstep(X2Int<0>{}, kc0, X2Int<0>{}, X2Int<0>{}); kstep(X2Int<1>{}, kc0 + 1, X2Int<0>{}, X2Int<0>{}); }
+              kstep(X2Int<0>{}, KC - 2, X2Int<0>{}, X2Int<1>{});
+              kstep(X2Int<1>{}, KC - 1, X2Int<1>{}, X2Int<1>{});
+          } else {
+              for (int kc0 = 0; kc0 < KC; kc0 += 2) { kstep(X2Int<0>{}, kc0, X2Int<1>{}, X2Int<1>{}); kstep(X2Int<1>{}, kc0 + 1, X2Int<1>{}, X2Int<1>{}); }
+          }
           // pass complete: unscale, add the bias, store the logits, update the statistics.  V % 128 == 0: a lane's two 4-column
           // groups exist or not for the whole wave.  The row loop is ONE basic block per case; the store address is a scalar
           // row pointer + one 32-bit per-lane offset.

@@ -148,3 +148,44 @@ def test_decode_follows_engine_optimizer_steps(golden_dir, capturable):
             graph.replay()
             seen.append(check(f"replayed step {i}"))
     assert len({tuple(s) for s in seen}) >= 3, "the steps were meant to change what the model decodes"
+
+
+@pytest.mark.parametrize("where", ["frame", "text"])
+def test_persistent_decode_leaves_activations_beyond_its_factored_tanh_to_the_other_loop(golden_dir, where):
+    """The persistent launch computes tanh(e + p) as 1 - 2 / (1 + exp 2e * exp 2p), exact while |e|, |p| <= 30.  Beyond that the two
+    factors cannot simply be clamped (enc = 40, text = -35: the clamped product says tanh(0), the truth is tanh(5)): the launch reports
+    state[7] = 10 (an audio frame) / 11 (a text vector) and decodes nothing; RNNTModel.greedy_decode / _many then take the kernel-per-layer
+    loop (tanh of the sum) without a warning, direct callers get a RuntimeError.  Tokens equal the numpy oracle's.  (Round-5 advice.)"""
+    import warnings
+
+    import rnnt_amd
+    c = load_decode_case(golden_dir, "decode_small")
+    frames, pred_sd, joint_sd = c["frames"].copy(), dict(c["pred_sd"]), dict(c["joint_sd"])
+    if where == "frame":
+        frames[3::7, 5] = 40.0    # with text ~ -2 the truth stays tanh(38) = 1; clamped factors would still agree here ...
+        frames[3::7, 6] = -41.0
+        pred_sd["output_layer_norm.bias"] = pred_sd["output_layer_norm.bias"].copy()
+        pred_sd["output_layer_norm.bias"][5] = -36.0   # ... but not here: 40 - 36 = 4 -> tanh(4), clamped: tanh(30 - 30) = 0
+    else:
+        w = pred_sd["output_layer_norm.weight"].copy()
+        w[::11] *= 40.0  # every 11th text feature up to ~100 in magnitude
+        pred_sd["output_layer_norm.weight"] = w
+    want, margins = decode_oracle.greedy_decode(frames, pred_sd, joint_sd, max_length=60)
+    assert margins.min() > 1e-3 and len(want) > 3
+    model = build_model(c["spec"], pred_sd, joint_sd)
+    mel = torch.from_numpy(np.ascontiguousarray(frames.T))[None].cuda()
+    lens = torch.tensor([mel.shape[-1]], device="cuda")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the range fallback is an exact path, not a degraded one: no warning
+        assert model.greedy_decode(mel, lens, max_length=60, persistent=True) == want
+        assert model.greedy_decode(mel, lens, max_length=60) == want
+        assert model.greedy_decode_many([mel, mel], max_length=60) == [want, want]
+    assert model.greedy_decode(mel, lens, max_length=60, scan_frames=0) == want
+    tl = getattr(model.joint, "text_ln", None)
+    state, _ = rnnt_amd.engine.greedy_decode_persistent(
+        mel[0].T.contiguous(), model.predictor._params(), 1e-5, None if tl is None else tl.weight, None if tl is None else tl.bias,
+        model.joint.joint_ln.weight, model.joint.joint_ln.bias, model.joint.blank_idx, 60)
+    st = state.tolist()
+    assert st[7] == (10 if where == "frame" else 11), st
+    with pytest.raises(RuntimeError, match="beyond"):
+        rnnt_amd.engine.check_decode_state(st)
