@@ -67,7 +67,7 @@ int check_dims(int B, int T, int U1, int H, int V, int dtype, bool need_h)
 
 int dw_splits(int B, int T, int H, int V, int dtype)
 {
-    const long tiles = dtype != RNNT_DTYPE_F32 ? (long)((V + 255) / 256) * ((H + 255) / 256) : dw_tiles(H, V);
+    const long tiles = dtype == RNNT_DTYPE_F32 ? dw_tiles(H, V) : dtype == RNNT_DTYPE_F32_F16X2 ? x2_dw_tiles(H, V) : (long)((V + 255) / 256) * ((H + 255) / 256);
     long s = 256 / tiles;
     if (s < 1) s = 1;
     if (s > (long)B * T) s = (long)B * T;

@@ -194,6 +194,7 @@ bool x2_linear_ok(int M, int K, int N);
 void launch_linear_x2_fwd(const float *x, long ldx, const float *W, const float *bias, int M, int K, int N, float *y, void *ws, hipStream_t st);
 void launch_linear_x2_bwd(const float *x, long ldx, const float *W, const float *dy, int M, int K, int N, float *dx, float *dW, float *db, void *ws,
                           hipStream_t st);
+int x2_dw_tiles(int H, int V);  // workgroup tiles per split of launch_dw_x2 (k_dw_x2 / k_dw_x2m)
 void launch_dw_x2(const X3Args &a, hipStream_t st, bool build_table = true, bool zero_prog = true);  // k_dw_x2<4> (k_dw_x2<4, true> when H % 256 == 128); -DRNNT_LAB builds: also k_dw_x2<8> / k_dw_x2p behind RNNT_VARIANT_X2_DW_8W / _P16
 
 // ---- decode.hip

@@ -586,6 +586,298 @@ __global__ __launch_bounds__(64 * NW, 1) void k_dw_x2(X3Args a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_dw_x2m (round 6): dW for H % 256 == 128 with at least two whole 256-column h blocks and an even number of v blocks (config 4:
+// H = 640, V = 1024).  k_dw_x2<4, true> covers the odd last 128 columns with one half-empty 256 x 256 tile per v block: two of its four
+// waves run no MFMAs, the workgroup naps in the split's lockstep, and the split count is sized for 3 tiles per v block although only 2.5
+// tiles' worth of products exist (config 4: 12 tiles x 21 splits, dW 13 % over its time per cell at config 2).  Here the odd block of TWO v
+// blocks is one TALL tile — 512 v x 128 h, four waves stacked along v, wave tile 128 x 128 as everywhere (16 accumulator tiles, 48 MFMAs per
+// k-step: every wave of every workgroup works) — beside the ordinary 256 x 256 tiles of the whole h blocks: (V/256) (H/256) + V/512 tiles
+// per split (config 4: 10 tiles x 25 splits).  A tall tile stages 4 G operand tiles (one per wave: the wave's own A rows) and 1 hidden
+// operand tile (its 8 DMA pieces per stage shared out two per wave): 40 KiB per k-step instead of 32, a 5-tile ring = 160 KiB of LDS.
+// The kernel's two tile kinds are two complete copies of the loop behind ONE workgroup-uniform branch (a branch inside the k loop would split
+// the hand-placed MFMA / DMA / read schedule into scheduling regions); everything else — ring stage layout, source-side swizzle, transposed
+// reads, the three products, db on the matrix pipe (whole h blocks 0 and 1 only), live-row table, soft lockstep, slab epilogue — is
+// k_dw_x2<4>'s, statement for statement.
+// ---------------------------------------------------------------------------------------
+#ifndef X2_DW_MIXED
+#define X2_DW_MIXED 1  // 0 (diagnostic builds): k_dw_x2<4, true> everywhere, round 5's form — the A/B partner of k_dw_x2m
+#endif
+int x2_dw_mixed_ok(int H, int V) { return X2_DW_MIXED && H % 256 == 128 && H >= 640 && V % 512 == 0; }
+int x2_dw_tiles(int H, int V) { return x2_dw_mixed_ok(H, V) ? (V / 256) * (H / 256) + V / 512 : ((V + 255) / 256) * ((H + 255) / 256); }
+
+__global__ __launch_bounds__(256, 1) void k_dw_x2m(X3Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) char s_ring[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int H = a.H, V = a.V;
+    const int n_vblk = V / 256, n_fh = H / 256;  // whole h blocks; the odd block = columns 256 n_fh .. +127
+    const int n_full = n_vblk * n_fh, tiles = n_full + n_vblk / 2;
+    const int total = tiles * a.n_split;
+    int id = blockIdx.x;  // XCD-aware remap: the tiles of one split share an XCD's L2
+    {
+        const int q8 = total / 8, r8 = total % 8, x = id % 8;
+        id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + id / 8;
+    }
+    const int tile = id % tiles, split = id / tiles;
+    const long *tab = a.dw_tab;
+    const int B = a.B;
+    const long nlive = tab[2 * B + 1];
+    const long g_lo = nlive * split / a.n_split, g_hi = nlive * (split + 1) / a.n_split;
+    const unsigned sel0 = (lane & 31) == 0 ? 0x3c003c00u : 0u;  // fp16 ones in column 0 of the selector fragment
+
+    auto body = [&](auto tall_c) {
+        constexpr bool TALL = decltype(tall_c)::value != 0;
+        // tile geometry.  Whole-block tile: (vb, hb), waves 2 (v) x 2 (h).  Tall tile: v blocks 2 vt, 2 vt + 1, the odd h block, waves 4 (v) x 1
+        const int vb = TALL ? 0 : tile / n_fh, hb = TALL ? n_fh : tile % n_fh, vt = TALL ? tile - n_full : 0;
+        const int wm = TALL ? wave : wave >> 1, wn = TALL ? 0 : wave & 1;
+        const int v0 = TALL ? vt * 512 + wave * 128 : vb * 256 + wm * 128;
+        const int h0 = TALL ? n_fh * 256 : hb * 256 + wn * 128;
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+            for (int qn = 0; qn < 4; ++qn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[qm][qn][r] = 0.f;
+        // db as in k_dw_x2<4>: the waves of the whole-block tiles of h blocks 0 and 1 each take one of their wm half's four M tiles
+        const bool do_b = !TALL && hb < 2;  // workgroup-uniform
+        const int bsel0 = (hb & 1) * 2 + wn;
+        f32x16 dacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+
+        if (g_hi > g_lo) {
+            // ---- DMA sources.  Own operand tile (8 pieces per stage): whole-block tile: waves 0, 1 the G tile's 128-column halves, waves 2, 3
+            // the hidden tile's; tall tile: every wave the 128 G columns of its own A rows.  Tall tile, in addition: pieces 2 (wave & 1),
+            // 2 (wave & 1) + 1 of plane wave >> 1 of the ONE hidden operand tile all four waves multiply by.
+            const bool is_g = TALL || wave < 2;
+            const int col0 = TALL ? v0 : (is_g ? vb : hb) * 256 + 128 * (wave & 1);
+            const char *pbase[2];
+            long rstride;
+            if (is_g) {
+                pbase[0] = (const char *)a.logits + 4L * col0;        // hi: first 64 bytes of each 128-byte chunk
+                pbase[1] = (const char *)a.logits + 4L * col0 + 64;   // mid: last 64
+                rstride = 4L * V;
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) pbase[p] = (const char *)(a.hidden + p * a.plane_stride) + 2L * col0;
+                rstride = 2L * H;
+            }
+            int soff[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jg = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
+                const int cb = is_g ? 128 * (jg >> 2) + 16 * (jg & 3) : 16 * jg;
+                soff[i] = (int)((4 * i + (lane >> 4)) * rstride) + cb - 1024 * i;  // (the piece's immediate offset 1024 i advances the memory address too)
+            }
+            const int xp = wave >> 1, xi0 = 2 * (wave & 1);  // tall: this wave's two pieces of the hidden tile — plane xp, pieces xi0, xi0 + 1
+            const char *xbase = (const char *)(a.hidden + xp * a.plane_stride) + 2L * h0;
+            const long xstride = 2L * H;
+            int xoff[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = xi0 + k;
+                const int jg = (lane & 15) ^ (((lane >> 4) << 2) | (i & 3));
+                xoff[k] = (int)((4 * i + (lane >> 4)) * xstride) + 16 * jg;
+            }
+            long row_first = 0;
+            // ---- transposed fragment reads (k_dw_x2's): A from operand tile wm (tall: wave), B from the hidden tile(s)
+            const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, hh = g >> 1;
+            const int lds0 = (int)(size_t)(lds_vptr)s_ring;
+            const int a_tile = TALL ? wave : wm;            // operand tile holding this wave's A rows
+            const int own_tile = TALL ? wave : wave;        // operand tile this wave stages
+            int abase[4][2], bbase[4][2], sbase[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int sec = 0; sec < 2; ++sec) {
+                    const int row = 8 * hh + 4 * sec + q;
+                    const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+                    const int ch = 4 * m + 2 * (g & 1) + (pp >> 1);
+                    abase[m][sec] = lds0 + a_tile * XW2_TILE + 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+                    bbase[m][sec] = lds0 + (TALL ? 4 : 2 + wn) * XW2_TILE + 256 * row + 16 * (ch ^ swz) + 8 * (pp & 1);
+                    if (m == (bsel0 & 3)) sbase[sec] = abase[m][sec];
+                }
+
+            auto kstep = [&](auto st_c, long ks, f32x16 &dacc) {
+                constexpr int ST = decltype(st_c)::value, DST = (ST + XW2_NST - 1) % XW2_NST;
+                __amdgpu_buffer_rsrc_t rs[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    rs[p] = __builtin_amdgcn_make_buffer_rsrc((void *)(pbase[p] + (row_first + (ks + XW2_NST - 1) * XW2_ROWS) * rstride), 0,
+                                                              (int)(XW2_ROWS * rstride), 0x00020000);
+                const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(xbase + (row_first + (ks + XW2_NST - 1) * XW2_ROWS) * xstride), 0, (int)(XW2_ROWS * xstride), 0x00020000);
+                auto dma_piece = [&](auto n_c) {  // piece n of this wave's share of stage ks+NST-1 -> ring stage DST
+                    constexpr int n = decltype(n_c)::value;
+                    if constexpr (n < 8) {
+                        constexpr int i = n & 3, p = (n >> 2) & 1;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[p], (lds_vptr)(s_ring + own_tile * XW2_TILE + DST * XW2_STAGE + p * XW2_PLANE),
+                                                                 16, soff[i], 0, 1024 * i, 0);
+                    } else {  // (tall) the hidden tile: operand tile 4
+                        constexpr int k = n - 8;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_vptr)(s_ring + 4 * XW2_TILE + DST * XW2_STAGE + xp * XW2_PLANE + 1024 * (xi0 + k)),
+                                                                 16, xoff[k], 0, 0, 0);
+                    }
+                };
+                auto reads = [&](X2Frag &f, const auto &base, auto p_c) {
+                    constexpr int off = ST * XW2_STAGE + decltype(p_c)::value * XW2_PLANE;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo[m]) : "v"(base[m][0]), "n"(off));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi[m]) : "v"(base[m][1]), "n"(off));
+                    }
+                };
+                // 16 MFMAs of one product with DMA pieces N0 .. N0+CNT-1 threaded through them (CNT <= 4: one per row of wave tiles)
+                auto product = [&](const X2Frag &fa_, const X2Frag &fb_, auto n0_c, auto cnt_c) {
+                    constexpr int N0 = decltype(n0_c)::value, CNT = decltype(cnt_c)::value;
+                    u32x4 fa[4], fb[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        fa[m] = u32x4{fa_.lo[m][0], fa_.lo[m][1], fa_.hi[m][0], fa_.hi[m][1]};
+                        fb[m] = u32x4{fb_.lo[m][0], fb_.lo[m][1], fb_.hi[m][0], fb_.hi[m][1]};
+                    }
+#pragma unroll
+                    for (int qm = 0; qm < 4; ++qm) {
+#pragma unroll
+                        for (int qn = 0; qn < 4; ++qn) acc[qm][qn] = x2_mfma(fa[qm], fb[qn], acc[qm][qn]);
+                        if (qm == 0 && CNT >= 1) dma_piece(X2Int<N0>{});
+                        if (qm == 1 && CNT >= 2) dma_piece(X2Int<N0 + (CNT >= 2 ? 1 : 0)>{});
+                        if (qm == 2 && CNT >= 4) dma_piece(X2Int<N0 + (CNT >= 4 ? 2 : 0)>{});
+                        if (qm == 3 && CNT >= 3) dma_piece(X2Int<N0 + (CNT >= 3 ? CNT - 1 : 0)>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                auto bias_read = [&](u32x2 &lo, u32x2 &hi, auto p_c) {
+                    constexpr int off = ST * XW2_STAGE + decltype(p_c)::value * XW2_PLANE;
+                    const int b0 = sbase[0], b1 = sbase[1];
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(b0), "n"(off));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(b1), "n"(off));
+                };
+                auto bias_mfma = [&](u32x2 &lo, u32x2 &hi, f32x16 &dacc) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) :: "memory");
+                    const u32x4 fa = {lo[0], lo[1], hi[0], hi[1]};
+                    const u32x4 sel = {sel0, sel0, sel0, sel0};
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(dacc) : "v"(fa), "v"(sel));
+                };
+                // stage ks landed (the ND (NST - 2) younger pieces of the stages after it may still fly); every wave is past its reads of
+                // stage ks-1, whose ring stage the DMAs below refill
+                static_assert(XW2_NST == 4, "counted waits below: two stages in flight behind the one waited for");
+                if (TALL) asm volatile(RNNT_VMCNT(20) ::: "memory");
+                else asm volatile(RNNT_VMCNT(16) ::: "memory");
+                x2_lds_barrier();
+                X2Frag Ah, Bh, Am, Bm;
+                u32x2 dl[2], dh[2];
+                reads(Ah, abase, X2Int<0>{});
+                reads(Bh, bbase, X2Int<0>{});
+                reads(Am, abase, X2Int<1>{});
+                X2_LANDED(Ah, 8);
+                X2_LANDED(Bh, 8);
+                product(Ah, Bh, X2Int<0>{}, X2Int<(TALL ? 4 : 3)>{});
+                reads(Bm, bbase, X2Int<1>{});
+                X2_LANDED(Am, 8);
+                product(Am, Bh, X2Int<(TALL ? 4 : 3)>{}, X2Int<3>{});
+                X2_LANDED(Bm, 0);
+                if (do_b) { bias_read(dl[0], dh[0], X2Int<0>{}); bias_read(dl[1], dh[1], X2Int<1>{}); }
+                product(Ah, Bm, X2Int<(TALL ? 7 : 6)>{}, X2Int<(TALL ? 3 : 2)>{});
+                if (do_b) { bias_mfma(dl[0], dh[0], dacc); bias_mfma(dl[1], dh[1], dacc); }
+            };
+            auto dma_stage = [&](long ks, int st) {  // pipeline prologue: this wave's pieces of stage ks
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const int p = n >> 2, i = n & 3;
+                    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(pbase[p] + (row_first + ks * XW2_ROWS) * rstride), 0, (int)(XW2_ROWS * rstride), 0x00020000);
+                    lds_vptr d = (lds_vptr)(s_ring + own_tile * XW2_TILE + st * XW2_STAGE + p * XW2_PLANE);
+                    if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, d, 16, soff[i], 0, 0, 0);
+                    if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, d, 16, soff[i], 0, 1024, 0);
+                    if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, d, 16, soff[i], 0, 2048, 0);
+                    if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, d, 16, soff[i], 0, 3072, 0);
+                }
+                if (TALL) {
+                    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(xbase + (row_first + ks * XW2_ROWS) * xstride), 0, (int)(XW2_ROWS * xstride), 0x00020000);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vptr)(s_ring + 4 * XW2_TILE + st * XW2_STAGE + xp * XW2_PLANE + 1024 * (xi0 + k)),
+                                                                 16, xoff[k], 0, 0, 0);
+                }
+            };
+
+            // soft lockstep of the tiles of a split (k_dw_x2's; tall and whole-block tiles walk the same k-steps and share G through L2)
+            constexpr int DW_LAG = 6, DW_NAPS = 256;
+            int *prog = a.dw_prog ? a.dw_prog + split * 16 : nullptr;
+            bool sync_on = prog != nullptr && tiles > 1 && tiles <= 16;
+            const int *nb = prog ? prog + (tile + 1 < tiles ? tile + 1 : 0) : nullptr;
+            int nb_at = 0x7fffffff;
+            int done = 0;
+            auto lockstep = [&](int mine) {  // (wave-uniform)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nb_at) :: "memory");
+                int naps = 0;
+                while (sync_on && nb_at + DW_LAG + XW2_NST < mine) {
+                    if (++naps > DW_NAPS) { sync_on = false; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(nb_at) : "s"(nb) : "memory");
+                }
+                if (sync_on) {
+                    if (tid == 0) __hip_atomic_store(prog + tile, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(nb_at) : "s"(nb) : "memory");
+                }
+            };
+            int ub = 0;
+            while (ub + 1 < B && tab[B + 1 + ub + 1] <= g_lo) ++ub;
+            for (long gq = g_lo; gq < g_hi; ++ub) {  // workgroup-uniform: one pipeline run per live range
+                const long cum0 = tab[B + 1 + ub], cum1 = ub + 1 < B ? tab[B + 1 + ub + 1] : nlive;
+                const long ge = cum1 < g_hi ? cum1 : g_hi;
+                if (ge <= gq) continue;
+                const long nks = 2 * (ge - gq);  // 16-cell k-steps of this range
+                row_first = (tab[ub] + (gq - cum0)) * XW2_GRAN;
+                gq = ge;
+                dma_stage(0, 0);
+                dma_stage(1, 1);
+                dma_stage(2, 2);
+                for (long ks = 0;;) {  // the ring stage of a k-step is ks % 4: unrolled by 4
+                    if (ks >= nks) break;
+                    lockstep(done + (int)ks);
+                    kstep(X2Int<0>{}, ks, dacc); ++ks;
+                    if (ks >= nks) break;
+                    kstep(X2Int<1>{}, ks, dacc); ++ks;
+                    if (ks >= nks) break;
+                    kstep(X2Int<2>{}, ks, dacc); ++ks;
+                    if (ks >= nks) break;
+                    kstep(X2Int<3>{}, ks, dacc); ++ks;
+                }
+                done += (int)nks;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the over-issued DMAs before the ring
+                x2_lds_barrier();                                  // is refilled / the kernel exits
+            }
+        }
+
+        // ---- epilogue: partial slab [split][V,H]; bias partial [split][V] (k_dw_x2's)
+        float *sw = a.slab_w + (long)split * V * H;
+        const float rw = a.dw_rescale, rb = a.db_rescale;
+#pragma unroll
+        for (int qm = 0; qm < 4; ++qm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = v0 + 32 * qm + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                for (int qn = 0; qn < 4; ++qn) sw[(long)v * H + h0 + 32 * qn + (lane & 31)] = acc[qm][qn][r] * rw;  // (V % 512 == 0, H % 128 == 0: every column exists)
+            }
+        if (do_b && (lane & 31) == 0) {  // column 0 of the selector products: lanes 0 / 32 store
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a.slab_b[(long)split * V + v0 + 32 * bsel0 + (r & 3) + 8 * (r >> 2) + 4 * half] = dacc[r] * rb;
+        }
+    };
+    if (tile >= n_full) body(X2Int<1>{});  // (workgroup-uniform)
+    else body(X2Int<0>{});
+}
+
 #ifdef RNNT_LAB
 #include "lab/x2_lab_dw.inc"  // k_dw_x2p (RNNT_VARIANT_X2_DW_P16): measured equal to k_dw_x2<4>, kept as lab equipment
 #endif
@@ -594,7 +886,7 @@ void launch_dw_x2(const X3Args &a, hipStream_t st, bool build_table, bool zero_p
 {
     if (build_table) launch_dw_table(a.logit_lens, a.B, a.T, a.U1, XW2_GRAN, a.dw_tab, st);
     if (a.dw_prog && zero_prog) launch_fill32(a.dw_prog, 0u, (size_t)a.n_split * 64, st);
-    const int tiles = ((a.V + 255) / 256) * ((a.H + 255) / 256);
+    const int tiles = x2_dw_tiles(a.H, a.V);
     static bool attr_set[16] = {false};  // > 64 KiB of dynamic LDS: opt-in once per device (read-mostly fact)
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
@@ -605,13 +897,16 @@ void launch_dw_x2(const X3Args &a, hipStream_t st, bool build_table, bool zero_p
         (void)hipFuncSetAttribute((const void *)k_dw_x2p, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
 #endif
         (void)hipFuncSetAttribute((const void *)k_dw_x2<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * XW2_TILE);
+        (void)hipFuncSetAttribute((const void *)k_dw_x2m, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * XW2_TILE);
         if (dev >= 0) attr_set[dev] = true;
     }
 #ifdef RNNT_LAB  // (the product build refuses these variants at the C boundary: engine.hip)
     if (a.flags & RNNT_VARIANT_X2_DW_P16) { hipLaunchKernelGGL(k_dw_x2p, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a); return; }
     if (a.flags & RNNT_VARIANT_X2_DW_8W) { hipLaunchKernelGGL(k_dw_x2<8>, dim3(tiles * a.n_split), dim3(512), 4 * XW2_TILE, st, a); return; }
 #endif
-    if (a.H % 256 != 0) hipLaunchKernelGGL((k_dw_x2<4, true>), dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
+    // H % 256 == 128: whole-block tiles + tall tiles over the odd block (k_dw_x2m) where the shape allows; else the half-empty last h block
+    if (x2_dw_mixed_ok(a.H, a.V)) hipLaunchKernelGGL(k_dw_x2m, dim3(tiles * a.n_split), dim3(256), 5 * XW2_TILE, st, a);
+    else if (a.H % 256 != 0) hipLaunchKernelGGL((k_dw_x2<4, true>), dim3(((a.V + 255) / 256) * ((a.H + 255) / 256) * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
     else hipLaunchKernelGGL(k_dw_x2<4>, dim3(tiles * a.n_split), dim3(256), 4 * XW2_TILE, st, a);
 }
 
@@ -2022,7 +2317,7 @@ LinWs lin_layout(int M, int K, int N, bool bwd)
     if (!bwd) { L.pack = o; o += al(x2_wpack_fwd_bytes(K, N)); L.total = o; return L; }
     L.rows_pad = ((long)M + 1 + 31) / 32 * 32;
     L.rows_alloc = (L.rows_pad + 96 + 127) / 128 * 128;
-    const long tiles = (long)((N + 255) / 256) * ((K + 255) / 256);
+    const long tiles = x2_dw_tiles(K, N);  // (the dW kernel's H = K, V = N)
     long ns = 256 / tiles;
     if (ns < 1) ns = 1;
     if (ns > L.rows_pad / 32) ns = L.rows_pad / 32;

@@ -74,6 +74,9 @@ FUSED_SHAPES = [
     # dPred slab heights in one reduction)
     (3, 21, 18, 1024, 64), (2, 10, 35, 768, 160), (2, 13, 6, 640, 1024), (2, 9, 4, 516, 96),
     (2, 19, 7, 1536, 32), (2, 11, 20, 1152, 96), (3, 33, 5, 1028, 64),
+    # H % 256 == 128 with whole h blocks beside the odd one and V % 512 == 0: the f16x2 route's dW runs whole-block AND tall tiles
+    # (k_dw_x2m, round 6) — three h blocks + the odd one, one v pair / two; ragged lengths split the live rows over 25 / 28 splits
+    (3, 40, 17, 896, 512), (2, 300, 20, 640, 1024),
     # BASELINE config 2's / config 4's lattice lengths through the whole fused pipeline at a joint small
     # enough for the oracle: 1 200 / 2 100 dependent sweep steps (chained waves / the barrier kernel of
     # lattices wider than the mailbox), alpha and beta around 1e3-1e4
