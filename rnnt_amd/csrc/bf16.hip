@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_joint_fwd_bf16(Bf16Args a)
 // ---------------------------------------------------------------------------------------
 // Diagnostic builds only (-DFR_EXP=bits, tools/build_bf16_variants.sh): parts of k_joint_fwd_bf16_ra compiled out —
 // 1 no MFMAs, 2 no statistics, 4 no logits stores, 8 no hidden stores, 16 no W DMA, 32 no tanh,
-// 64 one workgroup per CU (100 KiB of LDS requested)
+// 64 one workgroup per CU (100 KiB of LDS requested), 128 every W fragment feeds two MFMAs and half of W's DMA pieces are issued
 #ifndef FR_EXP
 #define FR_EXP 0
 #endif
@@ -681,13 +681,23 @@ __global__ __launch_bounds__(256, (KC <= 8 ? 2 : 1)) void k_joint_fwd_bf16_ra(Bf
             // this wave's share of chunk n+1 has landed.  vmcnt retires in order; younger than those DMAs are the 4
             // of chunk n+2 and, in the first two chunks of a pass, the 8 logits stores + the bias load of the epilogue
             // (the first pass's chunks 1 and 2 landed before the loop: no wait behind the hidden stores)
-            if (c < 2) { if (pass != 0) asm volatile(RNNT_VMCNT(12) ::: "memory"); }
+            if (FR_OFF(128)) { if (c < 2) { if (pass != 0) asm volatile(RNNT_VMCNT(10) ::: "memory"); } else asm volatile(RNNT_VMCNT(2) ::: "memory"); }
+            else if (c < 2) { if (pass != 0) asm volatile(RNNT_VMCNT(12) ::: "memory"); }
             else asm volatile(RNNT_VMCNT(4) ::: "memory");
             if (pass == 3) FRSTAMP(64 + 3 * c);
             lds_barrier();  // publishes chunk n+1; every wave is past its reads of chunk n-1 (slot of chunk n+3)
             if (pass == 3) FRSTAMP(65 + 3 * c);
             landed(g0, false);
             const int sb = rb + ((n & 3) << 14), sbn = rb + (((n + 1) & 3) << 14);
+            if (FR_OFF(128)) {  // what-if (wrong results): every W fragment feeds TWO MFMAs and half of W's bytes move — the price list of a 256-cell tile
+                mma4(BInt<(c == 0)>{}, A[c][0], g0, n, 0);
+                reads(g1, sb, BInt<2>{});
+                mma4(BInt<0>{}, A[c][1], g0, n, 5);
+                landed(g1, true);
+                mma4(BInt<0>{}, A[c][2], g1, n, 2);
+                reads(g0, sbn, BInt<0>{});
+                mma4(BInt<0>{}, A[c][3], g1, n, 5);
+            } else {
             reads(g1, sb, BInt<1>{});
             mma4(BInt<(c == 0)>{}, A[c][0], g0, n, 0);
             landed(g1, true);
@@ -699,6 +709,7 @@ __global__ __launch_bounds__(256, (KC <= 8 ? 2 : 1)) void k_joint_fwd_bf16_ra(Bf
             landed(g1, true);
             reads(g0, sbn, BInt<0>{});  // first group of chunk n+1 (published above; past the end: an unused landed slot)
             mma4(BInt<0>{}, A[c][3], g1, n, 3);
+            }
             if (pass == 3) FRSTAMP(66 + 3 * c);
         };
         if constexpr (KC >= 1) chunk(BInt<0>{});

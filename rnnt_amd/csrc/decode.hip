@@ -469,7 +469,7 @@ typedef unsigned long long dp_u64;
 #define DP_CODE_FRAME_RANGE 10   // state[7]: an audio frame, or (11) a text vector, beyond it — not a decode, the caller takes the other loop
 #define DP_CODE_TEXT_RANGE 11
 #ifndef DP_SPIN_LIMIT
-#define DP_SPIN_LIMIT (1 << 21)  // polls (~1.5 us each) before a sweep gives up
+#define DP_SPIN_LIMIT (1 << 18)  // polls (~1.5 us each: ~0.4 s) before a sweep gives up — several times the longest kernel another stream can hold a compute unit with (a cfg4 training step: 0.2 s); round 5: 2^21 = 3 s of stall before the fallback
 #endif
 // -DDP_TEST_STALL=n (tools/check_decode_giveup.sh, with a small -DDP_SPIN_LIMIT): workgroup 1 leaves at iteration n without publishing — the
 // other workgroups must give up at their next sweep, report it in state[7] and leave: the "every spin is bounded" claim, exercised

@@ -8,9 +8,9 @@
 set -e
 cd "$(dirname "$0")/.."
 D=build_variants/bf16w
-FR="0 1 2 4 8 16 32 6 63"
-DH="0 1 2 4 8 16 32 12 63"
-BW="0 1 2 4 8 16 32 64 29"
+FR="${FR_LIST:-0 1 2 4 8 16 32 6 63}"
+DH="${DH_LIST:-0 1 2 4 8 16 32 12 63}"
+BW="${BW_LIST:-0 1 2 4 8 16 32 64 29}"
 if [ "$1" = build ]; then
   mkdir -p $D
   make -C rnnt_amd/csrc -j6 -s librnnt_engine.so

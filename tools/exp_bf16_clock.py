@@ -4,7 +4,7 @@ of each ran at (s_memtime / s_memrealtime stamps at its start and end), for one 
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LEGEND = {"FR_EXP": {1: "MFMAs", 2: "statistics", 4: "logits stores", 8: "hidden stores", 16: "W DMA", 32: "tanh", 64: "(one workgroup per CU)"},
+LEGEND = {"FR_EXP": {1: "MFMAs", 2: "statistics", 4: "logits stores", 8: "hidden stores", 16: "W DMA", 32: "tanh", 64: "(one workgroup per CU)", 128: "half of the W fragment reads and of the W DMA pieces (two MFMAs per fragment)"},
           "DH_EXP": {1: "MFMAs", 2: "G arithmetic", 4: "G stores", 8: "logits loads", 16: "W staging", 32: "epilogue"},
           "BW_EXP": {1: "MFMAs", 2: "db dot2", 4: "fragment reads", 8: "DMA bytes", 16: "DMA instructions", 32: "barrier", 64: "lockstep"}}
 
