@@ -306,13 +306,16 @@ int rnnt_engine_greedy_decode(const void *frames, int64_t frame_stride, int T, c
  * persistent launch: 16 - 128 workgroups stay resident for the whole utterance and hand scan candidates, the conv2 output and the
  * predictor's output to each other through tagged 8-byte words in the workspace (rnnt_amd/csrc/decode.hip, k_dec_persist), with
  * conv1 replaced by per-token table rows and joint.text_ln folded into the predictor's linear layer (tables and folded matrices
- * are rebuilt from the parameters on every call, in the workspace).  Same arguments, state and tokens as
- * rnnt_engine_greedy_decode without scan_frames / iterations / init (the block is 16 frames, the call is the whole decode);
- * state[5] = iterations, state[6] = workgroups, state[7] != 0: a hand-off never arrived and the loop gave up (state and tokens are
- * then not a decode; nothing is raised on the stream).  The call only enqueues; the caller synchronises once.
+ * come from `tables`, below: the caller's buffer, or rebuilt from the parameters inside this call).  Same arguments, state and tokens
+ * as rnnt_engine_greedy_decode without scan_frames / iterations / init (the block is 16 frames, the call is the whole decode);
+ * state[5] = iterations, state[6] = workgroups, state[7] != 0: the loop did NOT decode (state and tokens are then not a decode;
+ * nothing is raised on the stream) — 1..9: a hand-off never arrived within the bounded spin (~0.4 s: a workgroup was not resident)
+ * and the loop gave up; 10 / 11: an audio frame / a text vector holds an entry beyond +-30 or a non-finite one, where the loop's
+ * factored tanh(e + p) = 1 - 2 / (1 + exp 2e exp 2p) is not exact.  In every such case decode the utterance with
+ * rnnt_engine_greedy_decode, which needs no residency and takes tanh of the sum.  The call only enqueues; the caller synchronises once.
  * RNNT_ERR_UNSUPPORTED (call rnnt_engine_greedy_decode instead): H % 64 != 0, H / E / O > 1024, S > 4096, T + max_length >= 2^20,
- * a device with fewer compute units than workgroups.  Token lists equal rnnt_engine_greedy_decode's wherever the argmax is not a
- * rounding-level tie (sums are associated differently).
+ * a device with fewer compute units than workgroups or with less LDS per workgroup than the kernel keeps (100-138 KB).  Token lists
+ * equal rnnt_engine_greedy_decode's wherever the argmax is not a rounding-level tie (sums are associated differently).
  */
 int rnnt_engine_greedy_decode_persistent_workspace_bytes(int T, int S, int E, int O, int H, int V, int has_text, size_t *out);
 /* `tables`: NULL (the tables are rebuilt in the workspace by this call: ~0.13 ms) or a caller-owned buffer filled by

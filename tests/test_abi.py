@@ -192,3 +192,20 @@ def test_engine_sources_only_enqueue_kernels():
             if banned.search(code):
                 hits.append(f"{fn}:{ln}: {line.strip()}")
     assert not hits, "runtime calls the engine must not make:\n" + "\n".join(hits)
+
+
+def test_dw_split_count_follows_the_tile_count(lib):
+    """The split-K count of the dW stage is 256 // (workgroup tiles per split), and the f16x2 route's tile count at H % 256 == 128
+    (BASELINE config 4: H = 640) is whole-block tiles + one TALL tile per pair of v blocks over the odd 128 columns (k_dw_x2m, round 6:
+    10 tiles, 25 splits) — the half-empty third h block of round 5 made it 12 tiles, 21 splits.  Host logic only."""
+    from rnnt_amd.engine import WsLayout, dtype_code
+    def n_split(H, V, dtype):
+        L = WsLayout()
+        assert lib.rnnt_engine_workspace_layout(8, 4000, 601, H, V, dtype_code(dtype), ctypes.byref(L)) == 0
+        return L.n_split
+    assert n_split(640, 1024, "f16x2") == 25          # 4 x 2 whole-block tiles + 2 tall tiles
+    assert n_split(640, 1024, "bf16x3") == 21         # (its dW keeps the half-empty block: 12 tiles)
+    assert n_split(512, 1024, "f16x2") == 32          # 8 tiles
+    assert n_split(896, 1024, "f16x2") == 256 // 14   # 4 x 3 + 2
+    assert n_split(640, 768, "f16x2") == 256 // 9     # V % 512 != 0: no tall tiles (3 x 3)
+    assert n_split(384, 1024, "f16x2") == 256 // 8    # fewer than two whole h blocks: no tall tiles (4 x 2)
