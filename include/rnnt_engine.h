@@ -296,7 +296,7 @@ int rnnt_engine_conv_predictor_bwd(const int64_t *ids, int B, int U1, int S, int
  */
 int rnnt_engine_greedy_decode_workspace_bytes(int H, int V, int E, int O, int scan_frames, size_t *out);
 int rnnt_engine_greedy_decode(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p,
-                              int S, int E, int O, float ln_eps, const void *text_W, const void *text_b,
+                              int S, int E, int O, float ln_in_eps, float ln_out_eps, const void *text_W, const void *text_b,
                               const void *W, const void *bias, int H, int V, int blank, int max_length,
                               int max_per_frame, int scan_frames, int iterations, int init, int32_t *host_flag,
                               int32_t *state, int32_t *tokens, void *workspace, size_t ws_bytes, void *stream);
@@ -322,10 +322,10 @@ int rnnt_engine_greedy_decode_persistent_workspace_bytes(int T, int S, int E, in
  * rnnt_engine_greedy_decode_build_tables for the SAME parameters (conv2's pack, the conv1 tap tables, the folded text_ln): build once per
  * set of weights, decode any number of utterances — concurrently on several streams too (the tables are only read). */
 int rnnt_engine_greedy_decode_tables_bytes(int S, int E, int O, int H, int has_text, size_t *out);
-int rnnt_engine_greedy_decode_build_tables(const rnnt_conv_predictor_params *p, int S, int E, int O, float ln_eps, const void *text_W,
+int rnnt_engine_greedy_decode_build_tables(const rnnt_conv_predictor_params *p, int S, int E, int O, float ln_in_eps, const void *text_W,
                                            const void *text_b, int H, void *tables, size_t tables_bytes, void *stream);
 int rnnt_engine_greedy_decode_persistent(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p,
-                                         int S, int E, int O, float ln_eps, const void *text_W, const void *text_b,
+                                         int S, int E, int O, float ln_in_eps, float ln_out_eps, const void *text_W, const void *text_b,
                                          const void *W, const void *bias, int H, int V, int blank, int max_length,
                                          int max_per_frame, const void *tables, int32_t *host_flag, int32_t *state, int32_t *tokens,
                                          void *workspace, size_t ws_bytes, void *stream);

@@ -395,7 +395,7 @@ void launch_dec_loop(const DecLoopArgs &a, hipStream_t st)
     for (int it = 0; it < a.iterations; ++it) {
         // g1[p] = gelu(conv1(LN(embedding[token p]), x1[p-1], x1[p-2]))            predictor.py:214-219 (dropout: eval)
         hipLaunchKernelGGL(k_dec_gemv<2>, dim3((E + 3) / 4), dim3(256), 0, st, a.state, a.tokens, wp1, a.p.conv1_b, x1ring, 3, 3, E, E, 1,
-                           a.p.embedding, a.p.ln_in_w, a.p.ln_in_b, a.ln_eps, a.S, g1ring, 1, 7, x1ring);
+                           a.p.embedding, a.p.ln_in_w, a.p.ln_in_b, a.ln_in_eps, a.S, g1ring, 1, 7, x1ring);
         // g2 = gelu(conv2(g1[p-4 .. p]))                                            predictor.py:222-223
         hipLaunchKernelGGL(k_dec_gemv<0>, dim3((E + 3) / 4), dim3(256), 0, st, a.state, a.tokens, wp2, a.p.conv2_b, g1ring, 7, 5, E, E, 1,
                            nul, nul, nul, 0.f, 0, g2, 0, 0, (float *)nullptr);
@@ -1104,12 +1104,12 @@ static DecTablesLayout dec_tables_layout(int S, int E, int O, int H, int has_tex
 }
 size_t dec_tables_floats(int S, int E, int O, int H, int has_text) { return dec_tables_layout(S, E, O, H, has_text).total; }
 
-void launch_dec_build_tables(const rnnt_conv_predictor_params &p, int S, int E, int O, float ln_eps, const float *text_W, const float *text_b, int H,
+void launch_dec_build_tables(const rnnt_conv_predictor_params &p, int S, int E, int O, float ln_in_eps, const float *text_W, const float *text_b, int H,
                              float *tb, hipStream_t st)
 {
     const int has_text = text_W ? 1 : 0;
     const DecTablesLayout L = dec_tables_layout(S, E, O, H, has_text);
-    hipLaunchKernelGGL(k_dp_ln_rows, dim3(S), dim3(256), 0, st, p.embedding, p.ln_in_w, p.ln_in_b, ln_eps, E, tb + L.xe);
+    hipLaunchKernelGGL(k_dp_ln_rows, dim3(S), dim3(256), 0, st, p.embedding, p.ln_in_w, p.ln_in_b, ln_in_eps, E, tb + L.xe);
     launch_pack_conv_w(p.conv1_w, tb + L.wp1, E, E, 3, st);  // [tap][out][in]
     launch_pack_conv_w(p.conv2_w, tb + L.wp2, E, E, 5, st);
     {  // the three tap tables by ONE GEMM: [S, E] x [3E, E]^T (the [tap][out][in] pack read as one 3E x E matrix) -> tab[s][tap][out]
@@ -1170,7 +1170,7 @@ int launch_dec_persist(const DecLoopArgs &a, hipStream_t st)
     hipLaunchKernelGGL(k_dp_exp_frames, dim3(512), dim3(256), 0, st, a.frames, a.frame_stride, T, H, ws + L.eenc, a.state);
     const float *tb = (const float *)a.tables;
     if (!tb) {
-        launch_dec_build_tables(a.p, S, E, O, a.ln_eps, a.text_W, a.text_b, H, ws + L.tables, st);
+        launch_dec_build_tables(a.p, S, E, O, a.ln_in_eps, a.text_W, a.text_b, H, ws + L.tables, st);
         tb = ws + L.tables;
     }
     DecPersistArgs k;

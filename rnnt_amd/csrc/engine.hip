@@ -689,7 +689,7 @@ int rnnt_engine_greedy_decode_workspace_bytes(int H, int V, int E, int O, int sc
 
 // argument checks shared by the two decode entry points; fills `a` (workspace / iteration fields left to the caller)
 static int dec_check_args(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p, int S, int E, int O,
-                          float ln_eps, const void *text_W, const void *text_b, const void *W, const void *bias, int H, int V, int blank,
+                          float ln_in_eps, float ln_eps, const void *text_W, const void *text_b, const void *W, const void *bias, int H, int V, int blank,
                           int max_length, int max_per_frame, int32_t *host_flag, int32_t *state, int32_t *tokens, void *workspace,
                           DecLoopArgs &a)
 {
@@ -716,7 +716,7 @@ static int dec_check_args(const void *frames, int64_t frame_stride, int T, const
     if (blank < 0 || blank >= V) return fail(RNNT_ERR_INVALID_ARG, "blank=%d outside [0,%d)", blank, V);
     if ((uintptr_t)workspace & 255) return fail(RNNT_ERR_INVALID_ARG, "workspace must be 256-byte aligned");
     a.frames = (const float *)frames; a.frame_stride = (long)frame_stride; a.T = T;
-    a.p = *p; a.S = S; a.E = E; a.O = O; a.ln_eps = ln_eps;
+    a.p = *p; a.S = S; a.E = E; a.O = O; a.ln_in_eps = ln_in_eps; a.ln_eps = ln_eps;
     a.text_W = (const float *)text_W; a.text_b = (const float *)text_b;
     a.W = (const float *)W; a.bias = (const float *)bias; a.H = H; a.V = V; a.blank = blank;
     a.max_length = max_length; a.max_per_frame = max_per_frame; a.scan_frames = 0; a.iterations = 0; a.init = 1;
@@ -725,7 +725,7 @@ static int dec_check_args(const void *frames, int64_t frame_stride, int T, const
 }
 
 int rnnt_engine_greedy_decode(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p,
-                              int S, int E, int O, float ln_eps, const void *text_W, const void *text_b,
+                              int S, int E, int O, float ln_in_eps, float ln_eps, const void *text_W, const void *text_b,
                               const void *W, const void *bias, int H, int V, int blank, int max_length,
                               int max_per_frame, int scan_frames, int iterations, int init, int32_t *host_flag,
                               int32_t *state, int32_t *tokens, void *workspace, size_t ws_bytes, void *stream)
@@ -734,7 +734,7 @@ int rnnt_engine_greedy_decode(const void *frames, int64_t frame_stride, int T, c
     if (int rc = rnnt_engine_greedy_decode_workspace_bytes(H, V, E, O, scan_frames, &need)) return rc;
     if (iterations < 0) return fail(RNNT_ERR_INVALID_ARG, "iterations=%d", iterations);
     DecLoopArgs a;
-    if (int rc = dec_check_args(frames, frame_stride, T, p, S, E, O, ln_eps, text_W, text_b, W, bias, H, V, blank, max_length, max_per_frame,
+    if (int rc = dec_check_args(frames, frame_stride, T, p, S, E, O, ln_in_eps, ln_eps, text_W, text_b, W, bias, H, V, blank, max_length, max_per_frame,
                                 host_flag, state, tokens, workspace, a))
         return rc;
     if (ws_bytes < need) return fail(RNNT_ERR_WORKSPACE, "workspace %zu < required %zu bytes", ws_bytes, need);
@@ -782,7 +782,7 @@ int rnnt_engine_greedy_decode_tables_bytes(int S, int E, int O, int H, int has_t
     return RNNT_OK;
 }
 
-int rnnt_engine_greedy_decode_build_tables(const rnnt_conv_predictor_params *p, int S, int E, int O, float ln_eps, const void *text_W,
+int rnnt_engine_greedy_decode_build_tables(const rnnt_conv_predictor_params *p, int S, int E, int O, float ln_in_eps, const void *text_W,
                                            const void *text_b, int H, void *tables, size_t tables_bytes, void *stream)
 {
     size_t need;
@@ -797,12 +797,12 @@ int rnnt_engine_greedy_decode_build_tables(const rnnt_conv_predictor_params *p, 
     if (!text_W && O != H) return fail(RNNT_ERR_INVALID_ARG, "without text_ln the predictor's output dim (%d) must equal H (%d)", O, H);
     if ((uintptr_t)tables & 255) return fail(RNNT_ERR_INVALID_ARG, "tables must be 256-byte aligned");
     if (tables_bytes < need) return fail(RNNT_ERR_WORKSPACE, "tables %zu < required %zu bytes", tables_bytes, need);
-    launch_dec_build_tables(*p, S, E, O, ln_eps, (const float *)text_W, (const float *)text_b, H, (float *)tables, (hipStream_t)stream);
+    launch_dec_build_tables(*p, S, E, O, ln_in_eps, (const float *)text_W, (const float *)text_b, H, (float *)tables, (hipStream_t)stream);
     return launch_status("rnnt_engine_greedy_decode_build_tables");
 }
 
 int rnnt_engine_greedy_decode_persistent(const void *frames, int64_t frame_stride, int T, const rnnt_conv_predictor_params *p,
-                                         int S, int E, int O, float ln_eps, const void *text_W, const void *text_b,
+                                         int S, int E, int O, float ln_in_eps, float ln_eps, const void *text_W, const void *text_b,
                                          const void *W, const void *bias, int H, int V, int blank, int max_length,
                                          int max_per_frame, const void *tables, int32_t *host_flag, int32_t *state, int32_t *tokens,
                                          void *workspace, size_t ws_bytes, void *stream)
@@ -810,7 +810,7 @@ int rnnt_engine_greedy_decode_persistent(const void *frames, int64_t frame_strid
     if (T < 1 || S < 1 || max_length < 2) return fail(RNNT_ERR_INVALID_ARG, "T=%d S=%d max_length=%d", T, S, max_length);
     if (int rc = dec_persist_check(T, S, E, O, H, V, text_W ? 1 : 0, max_length)) return rc;
     DecLoopArgs a;
-    if (int rc = dec_check_args(frames, frame_stride, T, p, S, E, O, ln_eps, text_W, text_b, W, bias, H, V, blank, max_length, max_per_frame,
+    if (int rc = dec_check_args(frames, frame_stride, T, p, S, E, O, ln_in_eps, ln_eps, text_W, text_b, W, bias, H, V, blank, max_length, max_per_frame,
                                 host_flag, state, tokens, workspace, a))
         return rc;
     const size_t need = align_up(dec_persist_workspace_floats(T, S, E, O, H, V, text_W ? 1 : 0) * 4);

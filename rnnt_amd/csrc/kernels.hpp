@@ -205,7 +205,7 @@ void launch_argmax_scan(const float *logits, int K, int V, int blank, int t0, in
 // device-resident greedy decode (decode.hip)
 struct DecLoopArgs {
     const float *frames; long frame_stride; int T;  // [T,H] audio frames (after audio_ln), h-stride 1
-    rnnt_conv_predictor_params p; int S, E, O; float ln_eps;
+    rnnt_conv_predictor_params p; int S, E, O; float ln_in_eps, ln_eps;  // eps of input_layer_norm / output_layer_norm
     const float *text_W, *text_b;                   // joint.text_ln [H,O], [H] or NULL (then O == H)
     const float *W, *bias; int H, V, blank;         // joint_ln
     int max_length, max_per_frame, scan_frames, iterations;
@@ -236,5 +236,5 @@ size_t dec_persist_workspace_floats(int T, int S, int E, int O, int H, int V, in
 size_t dec_persist_lds_bytes(int E);
 int launch_dec_persist(const DecLoopArgs &a, hipStream_t st);  // hipSuccess, or why the kernel's LDS limit could not be raised (nothing launched);  // scan_frames / iterations / init of `a` are not used
 size_t dec_tables_floats(int S, int E, int O, int H, int has_text);
-void launch_dec_build_tables(const rnnt_conv_predictor_params &p, int S, int E, int O, float ln_eps, const float *text_W, const float *text_b, int H,
+void launch_dec_build_tables(const rnnt_conv_predictor_params &p, int S, int E, int O, float ln_in_eps, const float *text_W, const float *text_b, int H,
                              float *tables, hipStream_t st);

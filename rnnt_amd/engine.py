@@ -68,9 +68,9 @@ SIGNATURES = {
     "rnnt_engine_greedy_scan_workspace_bytes": "iiip",
     "rnnt_engine_greedy_scan": "pqqpppiiiiippzp",
     "rnnt_engine_greedy_decode_workspace_bytes": "iiiiip",
-    "rnnt_engine_greedy_decode": "pqipiiifppppiiiiiiiippppzp",
+    "rnnt_engine_greedy_decode": "pqipiiiffppppiiiiiiiippppzp",
     "rnnt_engine_greedy_decode_persistent_workspace_bytes": "iiiiiiip",
-    "rnnt_engine_greedy_decode_persistent": "pqipiiifppppiiiiipppppzp",
+    "rnnt_engine_greedy_decode_persistent": "pqipiiiffppppiiiiipppppzp",
     "rnnt_engine_greedy_decode_tables_bytes": "iiiiip",
     "rnnt_engine_greedy_decode_build_tables": "piiifppipzp",
     "rnnt_engine_grad_norm_workspace_bytes": "ipp",
@@ -572,6 +572,13 @@ def greedy_scan(enc, pred, W, bias, t0, nframes, blank):
     return out
 
 
+def _eps_pair(ln_eps):
+    """`ln_eps` of the decode entry points: one float (both LayerNorms of the ConvPredictor) or (input_layer_norm.eps, output_layer_norm.eps)."""
+    if isinstance(ln_eps, (tuple, list)):
+        return float(ln_eps[0]), float(ln_eps[1])
+    return float(ln_eps), float(ln_eps)
+
+
 class _PredParams(ctypes.Structure):  # include/rnnt_engine.h: rnnt_conv_predictor_params
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "embedding", "ln_in_w", "ln_in_b", "conv1_w", "conv1_b", "conv2_w", "conv2_b", "linear_w",
@@ -618,7 +625,7 @@ def greedy_decode_tables(pred_params, ln_eps, text_W, text_b, H):
         _check(lib().rnnt_engine_greedy_decode_tables_bytes(S, E, O, int(H), 1 if text_W is not None else 0, ctypes.byref(n)))
         tables = torch.empty(n.value, dtype=torch.uint8, device=dev)
         st = _PredParams(*[t.data_ptr() for t in params])
-        _check(lib().rnnt_engine_greedy_decode_build_tables(ctypes.byref(st), S, E, O, ctypes.c_float(ln_eps), _p(text_W), _p(text_b), int(H),
+        _check(lib().rnnt_engine_greedy_decode_build_tables(ctypes.byref(st), S, E, O, ctypes.c_float(_eps_pair(ln_eps)[0]), _p(text_W), _p(text_b), int(H),
                                                             _p(tables), ctypes.c_size_t(n.value), _stream(dev)))
         tables._keepalive = (params, text_W, text_b)
     return tables
@@ -643,7 +650,7 @@ def greedy_decode_persistent(frames, pred_params, ln_eps, text_W, text_b, W, bia
         state, tokens = both[:8], both[8:]
         st = _PredParams(*[t.data_ptr() for t in params])
         _check(lib().rnnt_engine_greedy_decode_persistent(
-            _p(frames), ctypes.c_int64(frames.stride(0)), T, ctypes.byref(st), S, E, O, ctypes.c_float(ln_eps),
+            _p(frames), ctypes.c_int64(frames.stride(0)), T, ctypes.byref(st), S, E, O, ctypes.c_float(_eps_pair(ln_eps)[0]), ctypes.c_float(_eps_pair(ln_eps)[1]),
             _p(text_W), _p(text_b), _p(W), _p(bias), H, V, int(blank), int(max_length), int(max_per_frame),
             _p(tables), None, _p(state), _p(tokens), _p(ws), ctypes.c_size_t(ws.numel()), _stream(dev)))
         state._keepalive = (frames, params, W, bias, text_W, text_b, tables)  # until the caller has synchronised
@@ -695,7 +702,7 @@ def greedy_decode_loop(frames, pred_params, ln_eps, text_W, text_b, W, bias, bla
         while done < bound and (done == 0 or int(flag[0]) == 0):
             it = min(chunk, bound - done)
             _check(lib().rnnt_engine_greedy_decode(
-                _p(frames), ctypes.c_int64(frames.stride(0)), T, ctypes.byref(st), S, E, O, ctypes.c_float(ln_eps),
+                _p(frames), ctypes.c_int64(frames.stride(0)), T, ctypes.byref(st), S, E, O, ctypes.c_float(_eps_pair(ln_eps)[0]), ctypes.c_float(_eps_pair(ln_eps)[1]),
                 _p(text_W), _p(text_b), _p(W), _p(bias), H, V, int(blank), int(max_length), int(max_per_frame),
                 scan_frames, it, 1 if done == 0 else 0, ctypes.c_void_p(flag.data_ptr()), _p(state), _p(tokens), _p(ws),
                 ctypes.c_size_t(ws.numel()), stream))

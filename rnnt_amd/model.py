@@ -64,8 +64,6 @@ class RNNTModel(torch.nn.Module):
         H, V = self.joint.joint_ln.in_features, self.joint.joint_ln.out_features
         if E % 4 or O % 4 or E > 1024 or O > 1024 or H % 8 or V % 4:
             return False
-        if float(p.input_layer_norm.eps) != float(p.output_layer_norm.eps):  # the device loop takes ONE LayerNorm eps
-            return False
         return hasattr(self.joint, "text_ln") or O == H
 
     def _decode_tables(self):
@@ -76,7 +74,7 @@ class RNNTModel(torch.nn.Module):
         ~0.13 ms; greedy_decode_many shares one build between all utterances of a call, greedy_decode lets the launch rebuild in place."""
         from . import engine
         tl = getattr(self.joint, "text_ln", None)
-        return engine.greedy_decode_tables(self.predictor._params(), float(self.predictor.output_layer_norm.eps),
+        return engine.greedy_decode_tables(self.predictor._params(), (float(self.predictor.input_layer_norm.eps), float(self.predictor.output_layer_norm.eps)),
                                            tl.weight if tl is not None else None, tl.bias if tl is not None else None,
                                            self.joint.joint_ln.in_features)
 
@@ -107,7 +105,7 @@ class RNNTModel(torch.nn.Module):
                 frames = self.joint.audio_ln(frames)
             frames = frames.float().contiguous()
             tl = getattr(self.joint, "text_ln", None)
-            args = (frames, self.predictor._params(), float(self.predictor.output_layer_norm.eps),
+            args = (frames, self.predictor._params(), (float(self.predictor.input_layer_norm.eps), float(self.predictor.output_layer_norm.eps)),
                     tl.weight if tl is not None else None, tl.bias if tl is not None else None,
                     self.joint.joint_ln.weight, self.joint.joint_ln.bias, self.joint.blank_idx, max_length)
             S, E = self.predictor.embedding.weight.shape
@@ -223,7 +221,7 @@ class RNNTModel(torch.nn.Module):
                     frames = self.joint.audio_ln(frames)
                 frames = frames.float().contiguous()
                 state, toks = engine.greedy_decode_persistent(
-                    frames, self.predictor._params(), float(self.predictor.output_layer_norm.eps),
+                    frames, self.predictor._params(), (float(self.predictor.input_layer_norm.eps), float(self.predictor.output_layer_norm.eps)),
                     tl.weight if tl is not None else None, tl.bias if tl is not None else None,
                     self.joint.joint_ln.weight, self.joint.joint_ln.bias, self.joint.blank_idx, max_length, max_per_frame=10,
                     tables=tables)

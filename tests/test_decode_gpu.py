@@ -189,3 +189,32 @@ def test_persistent_decode_leaves_activations_beyond_its_factored_tanh_to_the_ot
     assert st[7] == (10 if where == "frame" else 11), st
     with pytest.raises(RuntimeError, match="beyond"):
         rnnt_amd.engine.check_decode_state(st)
+
+
+def test_decode_with_different_layer_norm_eps(golden_dir):
+    """input_layer_norm.eps != output_layer_norm.eps (the reference constructs both with the default, a checkpoint or a subclass need
+    not): every device path takes the two values separately (round 5: one eps, or a fallback to the host loop) and decodes what the
+    oracle decodes with the same two values."""
+    from oracle import predictor_oracle as po
+    c = load_decode_case(golden_dir, "decode_small_proj")
+    model = build_model(c["spec"], c["pred_sd"], c["joint_sd"])
+    model.predictor.input_layer_norm.eps = 5.0
+    model.predictor.output_layer_norm.eps = 0.05
+    assert model._device_loop_ok(torch.zeros(1, 1, device="cuda"))
+    mel = torch.from_numpy(np.ascontiguousarray(c["frames"].T))[None].cuda()
+    lens = torch.tensor([mel.shape[-1]], device="cuda")
+    # the oracle with two eps values: predictor_oracle.forward takes one, so its two LayerNorms are evaluated here
+    orig = po._ln
+    calls = {"n": 0}
+
+    def ln_two_eps(x, w, b, eps):
+        calls["n"] += 1
+        return orig(x, w, b, 5.0 if calls["n"] % 2 == 1 else 0.05)  # forward(): input LayerNorm first, output LayerNorm second
+
+    po._ln = ln_two_eps
+    try:
+        want, margins = decode_oracle.greedy_decode(c["frames"], c["pred_sd"], c["joint_sd"], max_length=60)
+    finally:
+        po._ln = orig
+    assert margins.min() > 1e-3 and len(want) > 3 and want != c["tokens"][60]  # (the eps values matter)
+    all_paths(model, mel, lens, 60, want, "two eps")
