@@ -97,7 +97,7 @@ def test_engine_linear_fwd_bwd_vs_torch(M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(1, 128, 128), (37, 128, 256), (130, 384, 128), (408, 512, 1024), (2100, 1024, 640), (6432, 1024, 1024),
-                                   (513, 640, 1152)])
+                                   (513, 640, 1152), (700, 640, 512), (300, 896, 1024)])  # (the last two: dW on whole-block + tall tiles, k_dw_x2m)
 @pytest.mark.parametrize("xscale,gscale", [(1.0, 1.0), (1e-3, 40.0), (300.0, 1e-5)])
 def test_engine_linear_x2_fwd_bwd_vs_float64(M, K, N, xscale, gscale):
     """The projections on the f16x2 matrix pipes (rnnt_engine_linear_x2_fwd / _bwd, round 5: reference rnnt/joint.py:8-12,26-30 —
