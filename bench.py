@@ -39,6 +39,9 @@ CONFIGS = {
     "ref512": (8, 500, 100, 512, 1024),     # the same lattice at H = 512: like-for-like with ref1024
     "ref1024b": (32, 500, 103, 1024, 1024),  # U1 = 104: no dead rows in 8- or 16-wide u tiles
     "ref512b": (32, 500, 103, 512, 1024),
+    # one rank's batch under the reference's own training settings (config/basic_sp_convjs_fullcausal.yaml: pergpu_minibatch_size 4,
+    # max_joint_size 160000 = B*T*U): the size a user of rnnt/train.py actually calls the engine with
+    "train4": (4, 400, 100, 1024, 1024),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"; bf16x3 spends 6 bf16 products per fp32 product

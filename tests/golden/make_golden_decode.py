@@ -68,12 +68,29 @@ def reference_loop(predictor, joint, audio_features, max_length):
     return tokens[1:], np.asarray(margins)
 
 
+def reference_encoder_frames(spec, seed):
+    """(T, C) frames from the reference's AudioEncoder (reference rnnt/jasper.py) on a seeded mel, as rnnt/model.py:92-93 produces them."""
+    from rnnt.jasper import AudioEncoder, JasperBlock
+    torch.manual_seed(seed)
+    enc = AudioEncoder(input_features=16, prologue_kernel_size=5, prologue_stride=2, prologue_dilation=1,
+                       blocks=[JasperBlock(5, 32, 48, 0.0, 2, norm_type="instance")],
+                       epilogue_features=64, epilogue_kernel_size=7, epilogue_stride=1, epilogue_dilation=2,
+                       output_features=spec["H"], norm_type="instance").eval()
+    with torch.no_grad():
+        out = enc(torch.randn(1, 16, 2 * spec["T"]))  # (N, C, L)
+    frames = out.permute(0, 2, 1)[0].contiguous().numpy().astype(np.float32)
+    assert frames.shape == (spec["T"], spec["H"]), frames.shape
+    return frames
+
+
 def make(name, spec):
     ml0 = spec["max_lengths"][0]
     T = spec["T"]
     lo, hi = (max(spec["max_lengths"][1] + 3, T // 5), min(ml0 - 2, (3 * T) // 4)) if not spec.get("want_cap") else (10 * (T - 2), ml0 - 2)
     for seed in range(1000, 1040):
         frames, pred_sd, joint_sd = decode_case_arrays(spec, seed, 0.0)
+        if spec.get("encoder"):
+            frames = reference_encoder_frames(spec, seed)
         p32, j32 = build(spec, pred_sd, joint_sd, torch.float32)
         with torch.no_grad():
             probe = j32.single_forward(torch.from_numpy(frames[:1]), p32(torch.tensor([[spec["V"] - 1]]))[:, -1, :])
@@ -81,6 +98,8 @@ def make(name, spec):
         biases = [-40.0 * sigma] if spec.get("want_cap") else [round(float(b), 3) for b in sigma * np.linspace(5.0, -1.0, 25)]
         for bias in biases:
             frames, pred_sd, joint_sd = decode_case_arrays(spec, seed, bias)
+            if spec.get("encoder"):
+                frames = reference_encoder_frames(spec, seed)
             p32, j32 = build(spec, pred_sd, joint_sd, torch.float32)
             t32, _ = reference_loop(p32, j32, torch.from_numpy(frames)[None], ml0)
             if not lo <= len(t32) <= hi:

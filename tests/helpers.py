@@ -171,6 +171,9 @@ DECODE_CASES = {
     "decode_small_proj": dict(V=300, E=36, O=56, H=64, fa=40, ft=56, T=45, max_lengths=(60, 9), w_scale=20.0, store=True),
     "decode_cap": dict(V=32, E=48, O=64, H=64, fa=-1, ft=-1, T=14, max_lengths=(200, 37), w_scale=12.0, store=True,
                        want_cap=True),  # blank almost never wins: every frame runs into the 10-symbols-per-frame cap
+    # frames = the output of the REFERENCE's own AudioEncoder (rnnt/jasper.py: prologue, a JasperBlock, epilogue; instance norm) on a seeded mel,
+    # permuted as rnnt/model.py:93 does — what the decode sees behind a real encoder instead of N(0,1) frames (stored: they are data)
+    "decode_ref_encoder": dict(V=32, E=48, O=64, H=64, fa=-1, ft=-1, T=75, max_lengths=(60, 9), w_scale=12.0, store=True, encoder="jasper"),
     "decode_wide_vocab": dict(V=4000, E=64, O=192, H=192, fa=-1, ft=-1, T=90, max_lengths=(60, 9), w_scale=30.0, store=False),
     "decode_ref_widths": dict(V=1024, E=512, O=1024, H=1024, fa=-1, ft=-1, T=200, max_lengths=(200, 25), w_scale=30.0,
                               store=False),  # config/basic_sp_convjs_fullcausal.yaml:20-25,60-65
